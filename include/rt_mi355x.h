@@ -1,0 +1,157 @@
+/*
+ * rt_mi355x.h -- C ABI of librt_mi355x.so, the MI355X-native drop-in for the RayTracer/
+ * sub-project of ipilter/RayTracerTest.
+ *
+ * The reference's boundary is a C++ class in a static library (RayTracer/RayTracer.h:14-41,
+ * callback type RayTracer/RaytracerCallback.h:9); its only caller is
+ * OpenGLView/MainFrame.cpp:45,219-220,233,249,254,293,311,438.  This header is the flat
+ * extern "C" form of exactly that class -- one entry point per public method, same
+ * argument order, units and error behaviour -- so that any FFI (the header-only C++
+ * class in include/RayTracer.h, ctypes in raytracertest_amd/api.py, cgo, JNI ...) binds
+ * the same symbols.  Plain pointers and sizes only.
+ *
+ * Declared semantic change (BASELINE.json north_star): the OpenGL PBO interop is cut.  The
+ * pointer handed to the callbacks is a HOST-readable BGRA8 image (pinned memory owned by
+ * the tracer, valid until the next rt_tracer_resize / rt_tracer_destroy), not a device
+ * pointer as in RayTracerImpl.cu:272,304.
+ *
+ * Error behaviour follows the reference: nothing throws across the API.  Functions that
+ * the reference declares void either return void here or an int status that callers may
+ * ignore; the text of the last failure is kept (rt_tracer_last_error / rt_last_error).
+ */
+#ifndef RT_MI355X_H
+#define RT_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK              0
+#define RT_ERR_INVALID     1   /* bad argument (e.g. UploadScene size not a multiple of 3) */
+#define RT_ERR_NO_DEVICE   2   /* no usable HIP device: the HIP path is mandatory, there is no CPU fallback */
+#define RT_ERR_HIP         3   /* a HIP runtime call or kernel launch failed */
+#define RT_ERR_STATE       4
+
+#define RT_MATH_FMA        0u  /* default: the documented a*b+c shapes are fused (nvcc -fmad=true analogue) */
+#define RT_MATH_STRICT     1u  /* every source-level operation rounds separately */
+
+#define RT_FLAG_NO_FILTER  1u  /* disable the conservative wave-uniform rejections (debug / parity tests) */
+
+#define RT_BUF_RENDER      0   /* rows*W*4 float  RGBA accumulators   (mRenderBuffer)      */
+#define RT_BUF_COUNTS      1   /* rows*W   uint32 sample counts       (mSampleCountBuffer) */
+#define RT_BUF_IMAGE       2   /* rows*W   uint32 BGRA8               (mImageBuffer)       */
+#define RT_BUF_RNG         3   /* 6 planes of rows*W uint32: d, v0..v4 (mRandomStates)     */
+
+typedef struct rt_tracer rt_tracer;                      /* opaque: rt::RayTracer + rt::RayTracerImpl */
+typedef struct rt_float4 { float x, y, z, w; } rt_float4;   /* CUDA's float4, RayTracer.h:34 */
+
+/* rt::CallBackFunction, RaytracerCallback.h:9: (ColorPtr imageBuffer, size_t size in bytes) + user data.
+ * Runs on the tracer's render thread (RayTracerImpl.cu:256-272,287-305). */
+typedef void (*rt_callback_fn)(uint32_t* imageBuffer, size_t size, void* user);
+
+/* Extensions the reference has no way to express (all optional; zero-initialise + struct_size). */
+typedef struct rt_options {
+  uint32_t struct_size;        /* sizeof(rt_options) */
+  int32_t  device;             /* HIP device ordinal; the reference pins device 0 (GLCanvas.cpp:259-260) */
+  uint32_t full_height;        /* 0: the tracer owns the whole image.  Otherwise the image is
+                                  imageSize[0] x full_height and this tracer owns the row band
+                                  [row_begin, row_begin + imageSize[1])  (multi-GPU sharding) */
+  uint32_t row_begin;
+  uint32_t use_time_seed;      /* 1: seed = (uint32)time(NULL) like Random.cu:45 (default when no options) */
+  uint32_t math_mode;          /* RT_MATH_FMA | RT_MATH_STRICT */
+  uint64_t seed;               /* curand_init seed when use_time_seed == 0 */
+  uint32_t flags;              /* RT_FLAG_* */
+  uint32_t samples_in_flight;  /* samples of a pixel kept in registers per pass (1,2,4; 0 = auto) */
+  uint32_t lds_chunk;          /* triangles staged in LDS at a time (0 = auto) */
+  uint32_t reserved;
+} rt_options;
+
+/* ---- the reference's public methods, one to one -------------------------------------- */
+
+/* RayTracer::RayTracer, RayTracer.h:17-22.  imageSize = {width, height} pixels, fov in
+ * degrees, cameraAngles in radians.  cameraPosition is stored and ignored exactly like
+ * the reference (ThinLensCamera.cuh:54-57,132-141: the camera sits at the world origin). */
+int  rt_tracer_create(const uint32_t imageSize[2], const float cameraPosition[3],
+                      const float cameraAngles[2], float fov, float focalLength, float aperture,
+                      rt_tracer** out);
+int  rt_tracer_create_ex(const uint32_t imageSize[2], const float cameraPosition[3],
+                         const float cameraAngles[2], float fov, float focalLength, float aperture,
+                         const rt_options* options, rt_tracer** out);
+/* RayTracer::~RayTracer, RayTracer.h:23: cancels and joins a running trace. */
+void rt_tracer_destroy(rt_tracer* t);
+/* RayTracer::Trace, RayTracer.h:25-27: asynchronous; cancels+joins a previous run, clears
+ * the buffers, runs iterationCount launches of samplesPerIteration samples, fires the
+ * update callback when i > 0 && updateInterval > 0 && i % updateInterval == 0 and the
+ * finished callback at the end (not when stopped).  RayTracerImpl.cu:69-87,236-315. */
+int  rt_tracer_trace(rt_tracer* t, uint32_t iterationCount, uint32_t samplesPerIteration,
+                     uint32_t updateInterval);
+/* RayTracer::Stop, RayTracer.h:28: sets the cancel flag (granularity: one kernel). */
+void rt_tracer_stop(rt_tracer* t);
+/* RayTracer::Resize, RayTracer.h:29: new buffers, RNG states re-created.  (Joins a running
+ * trace first; the reference races here, RayTracerImpl.cu:94-103.) */
+int  rt_tracer_resize(rt_tracer* t, const uint32_t size[2]);
+/* RayTracer::SetCameraParameters, RayTracer.h:30-32 (fov degrees). */
+void rt_tracer_set_camera_parameters(rt_tracer* t, float fov, float focalLength, float aperture);
+/* RayTracer::RotateCamera, RayTracer.h:33: angles += delta (radians), matrix rebuilt. */
+void rt_tracer_rotate_camera(rt_tracer* t, const float angles[2]);
+/* RayTracer::UploadScene, RayTracer.h:34: count float4, three absolute vertices per
+ * triangle, .w ignored; count < 3 or count % 3 != 0 is rejected and the previous scene
+ * kept (RayTracerImpl.cu:121-125). */
+int  rt_tracer_upload_scene(rt_tracer* t, const rt_float4* hostData, size_t count);
+/* RayTracer::SetUpdateCallback / SetFinishedCallback, RayTracer.h:36-37. */
+void rt_tracer_set_update_callback(rt_tracer* t, rt_callback_fn fn, void* user);
+void rt_tracer_set_finished_callback(rt_tracer* t, rt_callback_fn fn, void* user);
+
+/* ---- additive extensions --------------------------------------------------------------- */
+
+/* Block until the render thread of the last rt_tracer_trace has ended.  Returns 1 when it
+ * ran to completion (finished callback fired), 0 when it was stopped or failed. */
+int  rt_tracer_wait(rt_tracer* t);
+/* Re-create the RNG states from an explicit seed (the reference has no seed control). */
+int  rt_tracer_set_seed(rt_tracer* t, uint64_t seed);
+/* Spheres: count float4 = centre xyz + radius (build-defined, Documentation/ray.sphere.png). */
+int  rt_tracer_upload_spheres(rt_tracer* t, const rt_float4* spheres, size_t count);
+/* Device-resident form of one Trace for throughput measurement and multi-GPU drivers:
+ * enqueue clear + iterationCount trace launches + conversion on the tracer's stream, no
+ * callbacks, no host synchronisation.  rt_tracer_sync waits for the stream. */
+int  rt_tracer_trace_enqueue(rt_tracer* t, uint32_t iterationCount, uint32_t samplesPerIteration);
+int  rt_tracer_sync(rt_tracer* t);
+/* Sum of the trace-kernel durations (HIP events on the tracer's stream) and number of
+ * trace-kernel launches since the last reset; reset_after != 0 clears both. */
+int  rt_tracer_kernel_time(rt_tracer* t, double* total_ms, uint64_t* launches, int reset_after);
+/* Copy one of the tracer's device buffers to host memory / to another device pointer. */
+int  rt_tracer_read_buffer(rt_tracer* t, int which, void* dst, size_t bytes);
+int  rt_tracer_copy_buffer_to_device(rt_tracer* t, int which, void* dst_device, size_t bytes);
+void* rt_tracer_device_pointer(rt_tracer* t, int which);
+size_t rt_tracer_buffer_bytes(rt_tracer* t, int which);
+/* Launch geometry actually used: out[0]=K, out[1]=lds_chunk, out[2]=dynamic LDS bytes,
+ * out[3]=grid.x, out[4]=grid.y, out[5]=n_tris, out[6]=n_spheres, out[7]=device. */
+int  rt_tracer_info(rt_tracer* t, uint32_t out[8]);
+const char* rt_tracer_last_error(rt_tracer* t);
+const char* rt_last_error(void);          /* for failures before a tracer exists */
+int  rt_device_count(void);
+const char* rt_version(void);
+
+/* ---- single-function device harnesses (parity tests) ---------------------------------- */
+/* n independent (ray, triangle) pairs through the device HitTriangle: rays n*6 (origin,
+ * un-normalised direction -> rt::Ray(o, d, true)), tris n*9 (a, b, c).  eps_mode 0 =
+ * kernel epsilon 1e-10f, 1 = unit-test epsilon FLT_EPSILON.  Outputs: hit n, tuv n*3,
+ * normal n*3 = normalize(cross(b-a, c-a)), point n*3 = ray.point(t). */
+int rt_dbg_hit_triangle(int device, uint32_t math_mode, uint32_t n, const float* rays,
+                        const float* tris, int eps_mode, int32_t* hit, float* tuv, float* normal,
+                        float* point);
+int rt_dbg_sincos(int device, uint32_t n, const float* x, float* s, float* c);
+/* states n*6 {d,v0..v4} advanced in place, out n*m uniforms in (0,1] */
+int rt_dbg_uniform(int device, uint32_t n, uint32_t m, uint32_t* states, float* out);
+/* thin-lens rays of the tracer's current camera for n (x, y) pixels with given RNG states */
+int rt_dbg_get_ray(rt_tracer* t, uint32_t n, const uint32_t* pixels, uint32_t* states, float* rays);
+/* host: curand_init(seed, subsequence, 0) restated -> state[6] */
+void rt_dbg_rng_init_host(uint64_t seed, uint64_t subsequence, uint32_t state[6]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_MI355X_H */

@@ -1,0 +1,222 @@
+"""ctypes binding of the CPU oracle (oracle/_build/liboracle.so).
+
+TEST INFRASTRUCTURE, NOT PRODUCT CODE: import this only from tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg.  The product package
+(raytracertest_amd) never imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "liboracle.so")
+
+STRICT, FMA = 0, 1
+
+
+def build(force=False):
+    """Compile the C restatement (gcc).  Building the checker is not using it."""
+    src = [os.path.join(_HERE, f) for f in ("oracle.c", "oracle_core.inc", "oracle.h", "Makefile")]
+    if force or not os.path.exists(_SO) or any(
+            os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
+        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return _SO
+
+
+class Camera(C.Structure):
+    _fields_ = [("angles", C.c_float * 2), ("fov", C.c_float), ("focal", C.c_float),
+                ("aperture", C.c_float), ("M", C.c_float * 16)]
+
+
+class Scene(C.Structure):
+    _fields_ = [("tris", C.POINTER(C.c_float)), ("n_tris", C.c_uint32),
+                ("spheres", C.POINTER(C.c_float)), ("n_spheres", C.c_uint32)]
+
+
+class Frame(C.Structure):
+    _fields_ = [("W", C.c_uint32), ("H", C.c_uint32), ("row0", C.c_uint32), ("rows", C.c_uint32),
+                ("render", C.POINTER(C.c_float)), ("counts", C.POINTER(C.c_uint32)),
+                ("rng", C.POINTER(C.c_uint32)), ("image", C.POINTER(C.c_uint32))]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        f32p, u32p = C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+        L.orc_rng_seed.argtypes = [C.c_uint64, u32p]
+        L.orc_rng_init.argtypes = [C.c_uint64, C.c_uint64, u32p]
+        L.orc_rng_next.argtypes = [u32p]
+        L.orc_rng_next.restype = C.c_uint32
+        L.orc_rng_uniform.argtypes = [u32p]
+        L.orc_rng_uniform.restype = C.c_float
+        L.orc_rng_jump_columns.argtypes = [u32p]
+        L.orc_rng_step_linear_n.argtypes = [u32p, C.c_uint64]
+        L.orc_rng_matpow_apply.argtypes = [C.c_uint64, u32p]
+        L.orc_sincos.argtypes = [C.c_float, f32p, f32p]
+        L.orc_tan_half.argtypes = [C.c_float]
+        L.orc_tan_half.restype = C.c_float
+        L.orc_ray_make.argtypes = [f32p, f32p, C.c_int, C.c_int, f32p]
+        L.orc_ray_point.argtypes = [f32p, C.c_float, C.c_int, f32p]
+        L.orc_hit_triangle.argtypes = [f32p, f32p, f32p, f32p, C.c_int, C.c_int, f32p, f32p, f32p]
+        L.orc_hit_triangle.restype = C.c_int
+        L.orc_triangle_normal.argtypes = [f32p, f32p, f32p, C.c_int, f32p]
+        L.orc_hit_sphere.argtypes = [f32p, f32p, C.c_int, f32p]
+        L.orc_hit_sphere.restype = C.c_int
+        L.orc_camera_init.argtypes = [C.POINTER(Camera), f32p, C.c_float, C.c_float, C.c_float]
+        L.orc_camera_rotate.argtypes = [C.POINTER(Camera), f32p]
+        L.orc_camera_set.argtypes = [C.POINTER(Camera), C.c_float, C.c_float, C.c_float]
+        L.orc_camera_pinhole.argtypes = [C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32,
+                                         C.c_uint32, C.c_int, f32p]
+        L.orc_camera_get_ray.argtypes = [C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32,
+                                         C.c_uint32, u32p, C.c_int, f32p]
+        L.orc_uniform_on_disk.argtypes = [u32p, f32p]
+        L.orc_radiance.argtypes = [C.POINTER(Scene), f32p, C.c_int, f32p]
+        L.orc_frame_rng_init.argtypes = [C.POINTER(Frame), C.c_uint64, C.c_int]
+        L.orc_frame_clear.argtypes = [C.POINTER(Frame)]
+        L.orc_trace_launch.argtypes = [C.POINTER(Scene), C.POINTER(Camera), C.POINTER(Frame),
+                                       C.c_uint32, C.c_int, C.c_int]
+        L.orc_convert.argtypes = [C.POINTER(Frame)]
+        L.orc_pack_color.argtypes = [C.c_float, C.c_float, C.c_float]
+        L.orc_pack_color.restype = C.c_uint32
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _up(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+# ---------------------------------------------------------------- single items
+def rng_init(seed, subsequence):
+    s = np.zeros(6, np.uint32)
+    lib().orc_rng_init(seed, subsequence, _up(s))
+    return s
+
+
+def rng_next(state):
+    return int(lib().orc_rng_next(_up(state)))
+
+
+def rng_uniform(state):
+    return np.float32(lib().orc_rng_uniform(_up(state)))
+
+
+def sincos(x):
+    s, c = C.c_float(), C.c_float()
+    lib().orc_sincos(np.float32(x), C.byref(s), C.byref(c))
+    return np.float32(s.value), np.float32(c.value)
+
+
+def ray_make(o, d, normalize=True, contract=FMA):
+    out = np.zeros(6, np.float32)
+    lib().orc_ray_make(_fp(_f32(o)), _fp(_f32(d)), int(normalize), contract, _fp(out))
+    return out
+
+
+def ray_point(ray, t, contract=FMA):
+    p = np.zeros(3, np.float32)
+    lib().orc_ray_point(_fp(_f32(ray)), np.float32(t), contract, _fp(p))
+    return p
+
+
+def hit_triangle(ray, v0, v1, v2, contract=FMA, eps_mode=0):
+    t, u, v = C.c_float(), C.c_float(), C.c_float()
+    hit = lib().orc_hit_triangle(_fp(_f32(ray)), _fp(_f32(v0)), _fp(_f32(v1)), _fp(_f32(v2)),
+                                 contract, eps_mode, C.byref(t), C.byref(u), C.byref(v))
+    return bool(hit), np.float32(t.value), np.float32(u.value), np.float32(v.value)
+
+
+def triangle_normal(a, b, c, contract=FMA):
+    n = np.zeros(3, np.float32)
+    lib().orc_triangle_normal(_fp(_f32(a)), _fp(_f32(b)), _fp(_f32(c)), contract, _fp(n))
+    return n
+
+
+def hit_sphere(ray, sph, contract=FMA):
+    t = C.c_float()
+    hit = lib().orc_hit_sphere(_fp(_f32(ray)), _fp(_f32(sph)), contract, C.byref(t))
+    return bool(hit), np.float32(t.value)
+
+
+def camera(angles=(0.0, 0.0), fov_deg=70.0, focal=10.0, aperture=4.0):
+    cam = Camera()
+    lib().orc_camera_init(C.byref(cam), _fp(_f32(angles)), fov_deg, focal, aperture)
+    return cam
+
+
+def pack_color(r, g, b):
+    return int(lib().orc_pack_color(np.float32(r), np.float32(g), np.float32(b)))
+
+
+# ---------------------------------------------------------------- frames
+class OracleTracer:
+    """Mirror of RayTracerImpl's device state for a row band, on the CPU.
+
+    RayTracerImpl.cu:17-46 (ctor), :69-87/:236-315 (Trace/TraceFunct), :94-103 (Resize),
+    :105-117 (camera), :119-177 (UploadScene)."""
+
+    def __init__(self, width, height, angles=(0.0, 0.0), fov_deg=70.0, focal=10.0, aperture=4.0,
+                 seed=1, row0=0, rows=None, contract=FMA, nthreads=1):
+        self.W, self.H = int(width), int(height)
+        self.row0 = int(row0)
+        self.rows = int(self.H - self.row0 if rows is None else rows)
+        self.contract, self.nthreads, self.seed = contract, nthreads, seed
+        self.cam = camera(angles, fov_deg, focal, aperture)
+        self.tris = np.zeros((0, 12), np.float32)
+        self.spheres = np.zeros((0, 4), np.float32)
+        n = self.rows * self.W
+        self.render = np.zeros((self.rows, self.W, 4), np.float32)
+        self.counts = np.zeros((self.rows, self.W), np.uint32)
+        self.rng = np.zeros((self.rows, self.W, 6), np.uint32)
+        self.image = np.zeros((self.rows, self.W), np.uint32)
+        assert n > 0
+        self._frame = Frame(self.W, self.H, self.row0, self.rows, _fp(self.render),
+                            _up(self.counts), _up(self.rng), _up(self.image))
+        lib().orc_frame_rng_init(C.byref(self._frame), seed, nthreads)
+
+    def upload_scene(self, float4s):
+        a = _f32(float4s).reshape(-1, 4)
+        if a.shape[0] < 3 or a.shape[0] % 3 != 0:      # RayTracerImpl.cu:121-125
+            return False
+        self.tris = np.ascontiguousarray(a.reshape(-1, 12))
+        return True
+
+    def upload_spheres(self, float4s):
+        self.spheres = np.ascontiguousarray(_f32(float4s).reshape(-1, 4))
+
+    def set_camera_parameters(self, fov_deg, focal, aperture):
+        lib().orc_camera_set(C.byref(self.cam), fov_deg, focal, aperture)
+
+    def rotate_camera(self, dangles):
+        lib().orc_camera_rotate(C.byref(self.cam), _fp(_f32(dangles)))
+
+    def _scene(self):
+        return Scene(_fp(self.tris), self.tris.shape[0], _fp(self.spheres), self.spheres.shape[0])
+
+    def launch(self, samples):
+        sc = self._scene()
+        lib().orc_trace_launch(C.byref(sc), C.byref(self.cam), C.byref(self._frame), samples,
+                               self.contract, self.nthreads)
+
+    def trace(self, iterations, samples_per_iteration):
+        lib().orc_frame_clear(C.byref(self._frame))            # RayTracerImpl.cu:242-243
+        for _ in range(iterations):                            # :246
+            self.launch(samples_per_iteration)                 # :249
+        lib().orc_convert(C.byref(self._frame))                # :295
+        return self.image

@@ -1,0 +1,330 @@
+"""Host-side mirror of rt::RayTracer (RayTracer/RayTracer.h:14-41) over the C ABI
+(include/rt_mi355x.h).  Same method names, argument order, units and error behaviour as
+the reference class, so that the parity tests read like a caller of the reference
+(OpenGLView/MainFrame.cpp:45,219-256).
+
+There is NO fallback: if librt_mi355x.so is missing or no HIP device is usable this
+module raises.  PyTorch is not involved here at all.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "lib", "librt_mi355x.so")
+
+MATH_FMA, MATH_STRICT = 0, 1
+FLAG_NO_FILTER = 1
+BUF_RENDER, BUF_COUNTS, BUF_IMAGE, BUF_RNG = 0, 1, 2, 3
+
+# every symbol include/rt_mi355x.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "rt_tracer_create", "rt_tracer_create_ex", "rt_tracer_destroy", "rt_tracer_trace",
+    "rt_tracer_stop", "rt_tracer_resize", "rt_tracer_set_camera_parameters",
+    "rt_tracer_rotate_camera", "rt_tracer_upload_scene", "rt_tracer_set_update_callback",
+    "rt_tracer_set_finished_callback", "rt_tracer_wait", "rt_tracer_set_seed",
+    "rt_tracer_upload_spheres", "rt_tracer_trace_enqueue", "rt_tracer_sync",
+    "rt_tracer_kernel_time", "rt_tracer_read_buffer", "rt_tracer_copy_buffer_to_device",
+    "rt_tracer_device_pointer", "rt_tracer_buffer_bytes", "rt_tracer_info",
+    "rt_tracer_last_error", "rt_last_error", "rt_device_count", "rt_version",
+    "rt_dbg_hit_triangle", "rt_dbg_sincos", "rt_dbg_uniform", "rt_dbg_get_ray",
+    "rt_dbg_rng_init_host",
+]
+
+
+class RtError(RuntimeError):
+    pass
+
+
+class Options(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("full_height", C.c_uint32),
+                ("row_begin", C.c_uint32), ("use_time_seed", C.c_uint32), ("math_mode", C.c_uint32),
+                ("seed", C.c_uint64), ("flags", C.c_uint32), ("samples_in_flight", C.c_uint32),
+                ("lds_chunk", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+CALLBACK = C.CFUNCTYPE(None, C.POINTER(C.c_uint32), C.c_size_t, C.c_void_p)
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def load_library():
+    """dlopen librt_mi355x.so and declare the ABI.  Raises if the extension is missing."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(_LIB_PATH):
+            raise RtError("HIP extension not built: %s is missing (run `python -m raytracertest_amd.build` "
+                          "or __graft_entry__.build()); there is no CPU fallback" % _LIB_PATH)
+        L = C.CDLL(_LIB_PATH)
+        vp, u32p, f32p = C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_float)
+        L.rt_tracer_create.argtypes = [u32p, f32p, f32p, C.c_float, C.c_float, C.c_float, C.POINTER(vp)]
+        L.rt_tracer_create_ex.argtypes = [u32p, f32p, f32p, C.c_float, C.c_float, C.c_float,
+                                          C.POINTER(Options), C.POINTER(vp)]
+        L.rt_tracer_destroy.argtypes = [vp]
+        L.rt_tracer_destroy.restype = None
+        L.rt_tracer_trace.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.rt_tracer_stop.argtypes = [vp]
+        L.rt_tracer_stop.restype = None
+        L.rt_tracer_resize.argtypes = [vp, u32p]
+        L.rt_tracer_set_camera_parameters.argtypes = [vp, C.c_float, C.c_float, C.c_float]
+        L.rt_tracer_set_camera_parameters.restype = None
+        L.rt_tracer_rotate_camera.argtypes = [vp, f32p]
+        L.rt_tracer_rotate_camera.restype = None
+        L.rt_tracer_upload_scene.argtypes = [vp, vp, C.c_size_t]
+        L.rt_tracer_set_update_callback.argtypes = [vp, CALLBACK, vp]
+        L.rt_tracer_set_update_callback.restype = None
+        L.rt_tracer_set_finished_callback.argtypes = [vp, CALLBACK, vp]
+        L.rt_tracer_set_finished_callback.restype = None
+        L.rt_tracer_wait.argtypes = [vp]
+        L.rt_tracer_set_seed.argtypes = [vp, C.c_uint64]
+        L.rt_tracer_upload_spheres.argtypes = [vp, vp, C.c_size_t]
+        L.rt_tracer_trace_enqueue.argtypes = [vp, C.c_uint32, C.c_uint32]
+        L.rt_tracer_sync.argtypes = [vp]
+        L.rt_tracer_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
+        L.rt_tracer_read_buffer.argtypes = [vp, C.c_int, vp, C.c_size_t]
+        L.rt_tracer_copy_buffer_to_device.argtypes = [vp, C.c_int, vp, C.c_size_t]
+        L.rt_tracer_device_pointer.argtypes = [vp, C.c_int]
+        L.rt_tracer_device_pointer.restype = vp
+        L.rt_tracer_buffer_bytes.argtypes = [vp, C.c_int]
+        L.rt_tracer_buffer_bytes.restype = C.c_size_t
+        L.rt_tracer_info.argtypes = [vp, u32p]
+        L.rt_tracer_last_error.argtypes = [vp]
+        L.rt_tracer_last_error.restype = C.c_char_p
+        L.rt_last_error.restype = C.c_char_p
+        L.rt_device_count.restype = C.c_int
+        L.rt_version.restype = C.c_char_p
+        L.rt_dbg_hit_triangle.argtypes = [C.c_int, C.c_uint32, C.c_uint32, f32p, f32p, C.c_int,
+                                          C.POINTER(C.c_int32), f32p, f32p, f32p]
+        L.rt_dbg_sincos.argtypes = [C.c_int, C.c_uint32, f32p, f32p, f32p]
+        L.rt_dbg_uniform.argtypes = [C.c_int, C.c_uint32, C.c_uint32, u32p, f32p]
+        L.rt_dbg_get_ray.argtypes = [vp, C.c_uint32, u32p, u32p, f32p]
+        L.rt_dbg_rng_init_host.argtypes = [C.c_uint64, C.c_uint64, u32p]
+        L.rt_dbg_rng_init_host.restype = None
+        _lib = L
+        return _lib
+
+
+def device_count():
+    return int(load_library().rt_device_count())
+
+
+def _f32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _u32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+class RayTracer:
+    """rt::RayTracer.  Reference methods keep their names: Trace, Stop, Resize,
+    SetCameraParameters, RotateCamera, UploadScene, SetUpdateCallback, SetFinishedCallback.
+    Callbacks receive (image, size_bytes): image is a host numpy view (rows, W) of BGRA8
+    uint32 valid during the call (the reference hands a device pointer: PBO interop is cut)."""
+
+    def __init__(self, imageSize, cameraPosition=(0.0, 0.0, 0.0), cameraAngles=(0.0, 0.0), fov=70.0,
+                 focalLength=10.0, aperture=4.0, *, seed=None, device=0, math_mode=MATH_FMA,
+                 full_height=0, row_begin=0, no_filter=False, samples_in_flight=0, lds_chunk=0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self._cbs = {}
+        size = np.array(imageSize, np.uint32)
+        opt = Options()
+        opt.struct_size = C.sizeof(Options)
+        opt.device = device
+        opt.full_height, opt.row_begin = full_height, row_begin
+        opt.use_time_seed = 1 if seed is None else 0          # Random.cu:45 when no seed is given
+        opt.seed = 0 if seed is None else int(seed)
+        opt.math_mode = math_mode
+        opt.flags = FLAG_NO_FILTER if no_filter else 0
+        opt.samples_in_flight, opt.lds_chunk = samples_in_flight, lds_chunk
+        rc = self._lib.rt_tracer_create_ex(_u32p(size), _f32p(np.array(cameraPosition, np.float32)),
+                                           _f32p(np.array(cameraAngles, np.float32)), fov, focalLength,
+                                           aperture, C.byref(opt), C.byref(self._h))
+        if rc != 0 or not self._h:
+            raise RtError("rt_tracer_create failed (%d): %s" % (rc, self._lib.rt_last_error().decode()))
+        self.width = int(size[0])
+        self.rows = int(size[1])
+
+    # ---- reference API -------------------------------------------------------------
+    def Trace(self, iterationCount, samplesPerIteration, updateInterval):
+        self._check(self._lib.rt_tracer_trace(self._h, iterationCount, samplesPerIteration, updateInterval))
+
+    def Stop(self):
+        self._lib.rt_tracer_stop(self._h)
+
+    def Resize(self, size):
+        s = np.array(size, np.uint32)
+        self._check(self._lib.rt_tracer_resize(self._h, _u32p(s)))
+        self.width, self.rows = int(s[0]), int(s[1])
+
+    def SetCameraParameters(self, fov, focalLength, aperture):
+        self._lib.rt_tracer_set_camera_parameters(self._h, fov, focalLength, aperture)
+
+    def RotateCamera(self, angles):
+        self._lib.rt_tracer_rotate_camera(self._h, _f32p(np.array(angles, np.float32)))
+
+    def UploadScene(self, hostData):
+        """hostData: (3N, 4) float32.  Like the reference, an invalid size is rejected
+        without raising (RayTracerImpl.cu:121-125); returns False in that case."""
+        a = np.ascontiguousarray(hostData, np.float32).reshape(-1, 4)
+        rc = self._lib.rt_tracer_upload_scene(self._h, a.ctypes.data, a.shape[0])
+        if rc == 1:
+            return False
+        self._check(rc)
+        return True
+
+    def SetUpdateCallback(self, callback):
+        self._set_cb("update", callback, self._lib.rt_tracer_set_update_callback)
+
+    def SetFinishedCallback(self, callback):
+        self._set_cb("finished", callback, self._lib.rt_tracer_set_finished_callback)
+
+    # ---- extensions ------------------------------------------------------------------
+    def Wait(self):
+        return bool(self._lib.rt_tracer_wait(self._h))
+
+    def SetSeed(self, seed):
+        self._check(self._lib.rt_tracer_set_seed(self._h, int(seed)))
+
+    def UploadSpheres(self, spheres):
+        a = np.ascontiguousarray(spheres, np.float32).reshape(-1, 4)
+        self._check(self._lib.rt_tracer_upload_spheres(self._h, a.ctypes.data, a.shape[0]))
+
+    def TraceEnqueue(self, iterationCount, samplesPerIteration):
+        self._check(self._lib.rt_tracer_trace_enqueue(self._h, iterationCount, samplesPerIteration))
+
+    def Sync(self):
+        self._check(self._lib.rt_tracer_sync(self._h))
+
+    def KernelTime(self, reset=True):
+        ms, n = C.c_double(), C.c_uint64()
+        self._lib.rt_tracer_kernel_time(self._h, C.byref(ms), C.byref(n), 1 if reset else 0)
+        return ms.value, n.value
+
+    def _read(self, which, dtype, shape):
+        out = np.empty(shape, dtype)
+        self._check(self._lib.rt_tracer_read_buffer(self._h, which, out.ctypes.data, out.nbytes))
+        return out
+
+    def RenderBuffer(self):
+        return self._read(BUF_RENDER, np.float32, (self.rows, self.width, 4))
+
+    def SampleCounts(self):
+        return self._read(BUF_COUNTS, np.uint32, (self.rows, self.width))
+
+    def Image(self):
+        return self._read(BUF_IMAGE, np.uint32, (self.rows, self.width))
+
+    def RngStates(self):
+        """(rows, W, 6) uint32 {d, v0..v4} per pixel (device layout is 6 planes)."""
+        planes = self._read(BUF_RNG, np.uint32, (6, self.rows, self.width))
+        return np.ascontiguousarray(np.moveaxis(planes, 0, -1))
+
+    def DevicePointer(self, which):
+        return self._lib.rt_tracer_device_pointer(self._h, which)
+
+    def CopyToDevice(self, which, dst_ptr, nbytes):
+        self._check(self._lib.rt_tracer_copy_buffer_to_device(self._h, which, dst_ptr, nbytes))
+
+    def Info(self):
+        out = np.zeros(8, np.uint32)
+        self._lib.rt_tracer_info(self._h, _u32p(out))
+        keys = ("samples_in_flight", "lds_chunk", "lds_bytes", "grid_x", "grid_y", "n_tris", "n_spheres", "device")
+        return dict(zip(keys, (int(v) for v in out)))
+
+    def LastError(self):
+        return self._lib.rt_tracer_last_error(self._h).decode()
+
+    def DebugGetRay(self, pixels, states):
+        pix = np.ascontiguousarray(pixels, np.uint32).reshape(-1, 2)
+        st = np.ascontiguousarray(states, np.uint32).reshape(-1, 6).copy()
+        rays = np.zeros((pix.shape[0], 6), np.float32)
+        self._check(self._lib.rt_dbg_get_ray(self._h, pix.shape[0], _u32p(pix), _u32p(st), _f32p(rays)))
+        return rays, st
+
+    def close(self):
+        if self._h:
+            self._lib.rt_tracer_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- internals -------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            raise RtError("librt_mi355x error %d: %s" % (rc, self.LastError()))
+
+    def _set_cb(self, key, callback, setter):
+        if callback is None:
+            self._cbs[key] = CALLBACK()
+            setter(self._h, self._cbs[key], None)
+            return
+        rows, width = self.rows, self.width
+
+        def tramp(ptr, size, _user):
+            n = size // 4
+            img = np.ctypeslib.as_array(ptr, shape=(n,))
+            callback(img.reshape(rows, width) if n == rows * width else img, size)
+        self._cbs[key] = CALLBACK(tramp)       # keep alive
+        setter(self._h, self._cbs[key], None)
+
+
+# ---- single-function device harnesses (parity tests) ------------------------------------
+def dbg_hit_triangle(rays, tris, math_mode=MATH_FMA, eps_mode=0, device=0):
+    L = load_library()
+    r = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+    t = np.ascontiguousarray(tris, np.float32).reshape(-1, 9)
+    n = r.shape[0]
+    hit = np.zeros(n, np.int32)
+    tuv, nrm, pt = (np.zeros((n, 3), np.float32) for _ in range(3))
+    rc = L.rt_dbg_hit_triangle(device, math_mode, n, _f32p(r), _f32p(t), eps_mode,
+                               hit.ctypes.data_as(C.POINTER(C.c_int32)), _f32p(tuv), _f32p(nrm), _f32p(pt))
+    if rc != 0:
+        raise RtError("rt_dbg_hit_triangle failed (%d): %s" % (rc, L.rt_last_error().decode()))
+    return hit.astype(bool), tuv, nrm, pt
+
+
+def dbg_sincos(x, device=0):
+    L = load_library()
+    a = np.ascontiguousarray(x, np.float32).ravel()
+    s, c = np.zeros_like(a), np.zeros_like(a)
+    rc = L.rt_dbg_sincos(device, a.size, _f32p(a), _f32p(s), _f32p(c))
+    if rc != 0:
+        raise RtError("rt_dbg_sincos failed (%d): %s" % (rc, L.rt_last_error().decode()))
+    return s, c
+
+
+def dbg_uniform(states, m, device=0):
+    L = load_library()
+    st = np.ascontiguousarray(states, np.uint32).reshape(-1, 6).copy()
+    out = np.zeros((st.shape[0], m), np.float32)
+    rc = L.rt_dbg_uniform(device, st.shape[0], m, _u32p(st), _f32p(out))
+    if rc != 0:
+        raise RtError("rt_dbg_uniform failed (%d): %s" % (rc, L.rt_last_error().decode()))
+    return out, st
+
+
+def dbg_rng_init_host(seed, subsequence):
+    s = np.zeros(6, np.uint32)
+    load_library().rt_dbg_rng_init_host(int(seed), int(subsequence), _u32p(s))
+    return s

@@ -1,0 +1,122 @@
+// rt_device_math.hpp -- gfx950 device arithmetic of the trace path.
+//
+// Numeric spec (DESIGN.md "numeric spec"): IEEE-754 binary32, correctly rounded / and
+// sqrt (hipcc default), denormals kept, the whole library compiled with
+// -ffp-contract=off so the ONLY fused multiply-adds are the explicit ones below.
+// Math<true>  ("fma", default): the a*b+c shapes nvcc's default -fmad=true would fuse in
+//                               the reference's GPU build (RayTracer/RayTracer.vcxproj:65-70).
+// Math<false> ("strict"):       every source-level operation rounds on its own.
+// Citations are to the reference: RayTracer/Kernels.cuh, ThinLensCamera.cuh, Ray.cuh,
+// Random.cuh, Random.cu, DeviceUtils.cuh.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rtd {
+
+struct V3 { float x, y, z; };
+
+__device__ __forceinline__ V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 add(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ float absf(float f) { return (f < 0.0f) ? -f : f; }   // Kernels.cuh:16-19
+
+template <bool FMA>
+struct Math {
+  // x*y - z*w
+  static __device__ __forceinline__ float msub2(float x, float y, float z, float w) {
+    if constexpr (FMA) return __builtin_fmaf(x, y, -(z * w));
+    else return (x * y) - (z * w);
+  }
+  // a*b + c*d
+  static __device__ __forceinline__ float madd2(float a, float b, float c, float d) {
+    if constexpr (FMA) return __builtin_fmaf(a, b, c * d);
+    else return (a * b) + (c * d);
+  }
+  // a*b + c
+  static __device__ __forceinline__ float madd1(float a, float b, float c) {
+    if constexpr (FMA) return __builtin_fmaf(a, b, c);
+    else return (a * b) + c;
+  }
+  // glm::cross
+  static __device__ __forceinline__ V3 cross(V3 a, V3 b) {
+    return {msub2(a.y, b.z, b.y, a.z), msub2(a.z, b.x, b.z, a.x), msub2(a.x, b.y, b.x, a.y)};
+  }
+  // glm::dot(vec3): (a.x*b.x + a.y*b.y) + a.z*b.z
+  static __device__ __forceinline__ float dot(V3 a, V3 b) {
+    if constexpr (FMA) return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.x, b.x, a.y * b.y));
+    else return ((a.x * b.x) + (a.y * b.y)) + (a.z * b.z);
+  }
+  // glm::normalize: v * (1 / sqrt(dot(v, v)))
+  static __device__ __forceinline__ V3 normalize(V3 a) {
+    const float inv = 1.0f / __builtin_sqrtf(dot(a, a));
+    return {a.x * inv, a.y * inv, a.z * inv};
+  }
+  // glm mat4 * vec4, xyz: (m0*x + m1*y) + (m2*z + m3*w); M holds the 4 columns' xyz
+  static __device__ __forceinline__ V3 mat_mul_point(const float* M, float x, float y, float z, float w) {
+    return {madd2(M[0], x, M[3], y) + madd2(M[6], z, M[9], w),
+            madd2(M[1], x, M[4], y) + madd2(M[7], z, M[10], w),
+            madd2(M[2], x, M[5], y) + madd2(M[8], z, M[11], w)};
+  }
+};
+
+// ---- build-owned sincos (replaces libdevice sinf/cosf; same constants and operation
+// order as the documented spec, every step an explicit fma) ------------------------------
+__host__ __device__ __forceinline__ void sincos_spec(float x, float& s, float& c) {
+  const float k = __builtin_rintf(x * 0.63661977236758134308f);
+  float r = __builtin_fmaf(k, -1.5703125f, x);
+  r = __builtin_fmaf(k, -4.837512969970703125e-4f, r);
+  r = __builtin_fmaf(k, -7.54978995489188216e-8f, r);
+  const float z = r * r;
+  const float ps = __builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z,
+                                  -1.6666654611e-1f);
+  const float sn = __builtin_fmaf(r * z, ps, r);
+  const float pc = __builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z,
+                                  4.166664568298827e-2f);
+  const float cs = __builtin_fmaf(z * z, pc, __builtin_fmaf(-0.5f, z, 1.0f));
+  const int q = static_cast<int>(k) & 3;
+  s = (q == 0) ? sn : (q == 1) ? cs : (q == 2) ? -sn : -cs;
+  c = (q == 0) ? cs : (q == 1) ? -sn : (q == 2) ? -cs : sn;
+}
+
+// ---- XORWOW (cuRAND's curandState_t generator restated; Random.cuh:15-16,23) ----------
+struct Rng { uint32_t d, v0, v1, v2, v3, v4; };
+
+__device__ __forceinline__ uint32_t rng_next(Rng& s) {
+  const uint32_t t = s.v0 ^ (s.v0 >> 2);
+  s.v0 = s.v1; s.v1 = s.v2; s.v2 = s.v3; s.v3 = s.v4;
+  s.v4 = (s.v4 ^ (s.v4 << 4)) ^ (t ^ (t << 1));
+  s.d += 362437u;
+  return s.v4 + s.d;
+}
+
+// curand_uniform: x * 2^-32 + 2^-33, (0, 1]
+__device__ __forceinline__ float rng_uniform(Rng& s) {
+  return static_cast<float>(rng_next(s)) * 2.3283064e-10f + (2.3283064e-10f / 2.0f);
+}
+
+// random::UnifromOnDisk, Random.cuh:13-19 (the mistyped pi literal is the reference's)
+__device__ __forceinline__ void uniform_on_disk(Rng& s, float& dx, float& dy) {
+  const float t = (2.0f * 3.14156545f) * rng_uniform(s);
+  const float u1 = rng_uniform(s);
+  const float u2 = rng_uniform(s);
+  const float u = u1 + u2;
+  const float sr = (u > 1.0f) ? 2.0f - u : u;
+  float sn, cs;
+  sincos_spec(t, sn, cs);
+  dx = sr * cs;
+  dy = sr * sn;
+}
+
+// float -> rt::Channel as the GPU conversion does it: truncate toward zero, clamp, NaN -> 0
+__device__ __forceinline__ uint32_t to_channel(float f) {
+  if (!(f > 0.0f)) return 0u;
+  if (f >= 255.0f) return 255u;
+  return static_cast<uint32_t>(f);
+}
+
+// utils::GetColor, DeviceUtils.cuh:20-23: b | g<<8 | r<<16 | a<<24
+__device__ __forceinline__ uint32_t pack_color(float r, float g, float b) {
+  return (to_channel(b) << 0) | (to_channel(g) << 8) | (to_channel(r) << 16) | (255u << 24);
+}
+
+}  // namespace rtd

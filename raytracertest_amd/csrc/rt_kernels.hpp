@@ -1,0 +1,44 @@
+// rt_kernels.hpp -- launch interface between the host runtime (rt_tracer.cpp) and the
+// gfx950 kernels (rt_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rtk {
+
+// Everything rt::TraceKernel receives by value (RayTracer/Kernels.cuh:110-118), for a row
+// band [row0, row0+rows) of a W x H image.
+struct TraceParams {
+  float4*   render;    // rows*W RGBA float accumulators (mRenderBuffer)
+  uint32_t* counts;    // rows*W sample counts          (mSampleCountBuffer)
+  uint32_t* rng;       // 6 planes of rows*W u32: d, v0..v4 (mRandomStates, SoA)
+  uint32_t  W, H;      // full image size (camera uses the full height)
+  uint32_t  row0, rows;
+  uint32_t  npix;      // rows*W
+  uint32_t  samples;   // sampleCount of this launch
+  float     cam[12];   // mCameraTransformation: xyz of the 4 columns
+  float     half_height, aspect, focal, aperture;
+  const float4* tri;        // 3 float4 per triangle: v0, e1 = v1-v0, e2 = v2-v0
+  const float4* tri_color;  // abs(normalize(cross(e1,e2)))
+  uint32_t  n_tris;
+  const float4* spheres;    // centre xyz, radius (build-defined extension)
+  uint32_t  n_spheres;
+  uint32_t  chunk;          // triangles staged into LDS at a time
+};
+
+hipError_t launch_rng_init(uint32_t* rng, uint32_t npix, uint32_t p0, const uint32_t seeded[6],
+                           const uint32_t* jump, hipStream_t st);
+hipError_t launch_prep_triangles(bool fma, const float4* verts, uint32_t n, float4* rec, float4* color,
+                                 hipStream_t st);
+hipError_t launch_trace(const TraceParams& p, bool fma, bool filter, int K, hipStream_t st);
+hipError_t launch_convert(const float4* render, const uint32_t* counts, uint32_t* image, uint32_t npix,
+                          hipStream_t st);
+
+hipError_t launch_dbg_hit_triangle(bool fma, uint32_t n, const float* rays, const float* tris, int eps_mode,
+                                   int* hit, float* tuv, float* normal, float* point, hipStream_t st);
+hipError_t launch_dbg_sincos(uint32_t n, const float* x, float* s, float* c, hipStream_t st);
+hipError_t launch_dbg_uniform(uint32_t n, uint32_t m, uint32_t* states, float* out, hipStream_t st);
+hipError_t launch_dbg_get_ray(bool fma, const TraceParams& p, uint32_t n, const uint32_t* pixels,
+                              uint32_t* states, float* rays, hipStream_t st);
+
+}  // namespace rtk

@@ -1,0 +1,742 @@
+// rt_tracer.hip -- host runtime behind the C ABI of include/rt_mi355x.h.
+//
+// Mirrors rt::RayTracerImpl (RayTracer/RayTracerImpl.cuh:17-75, RayTracerImpl.cu): owns the
+// device buffers, the RNG states, the scene, the camera, the render std::thread, launches
+// the kernels and fires the callbacks.  HIP streams/events, pinned host image for the
+// callbacks (the PBO interop is cut), no CPU fallback: without a HIP device creation fails.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <ctime>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/rt_mi355x.h"
+#include "rt_device_math.hpp"
+#include "rt_kernels.hpp"
+#include "rt_rng_host.hpp"
+
+namespace {
+
+std::mutex g_err_mu;
+std::string g_last_error;
+
+void set_global_error(const std::string& s) {
+  std::lock_guard<std::mutex> lk(g_err_mu);
+  g_last_error = s;
+  if (getenv("RT_MI355X_LOG")) fprintf(stderr, "[rt_mi355x] %s\n", s.c_str());
+}
+
+std::string fmt(const char* f, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, f);
+  vsnprintf(buf, sizeof buf, f, ap);
+  va_end(ap);
+  return buf;
+}
+
+struct HipFail { std::string what; };
+#define HIP_CHECK(expr)                                                                   \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess) throw HipFail{fmt("%s failed: %s", #expr, hipGetErrorString(e_))}; \
+  } while (0)
+
+// jump table: built once per process, uploaded once per device
+std::mutex g_jump_mu;
+std::vector<uint32_t> g_jump_host;
+std::map<int, uint32_t*> g_jump_dev;
+
+const std::vector<uint32_t>& jump_host() {
+  std::lock_guard<std::mutex> lk(g_jump_mu);
+  if (g_jump_host.empty()) g_jump_host = rth::build_jump_table();
+  return g_jump_host;
+}
+
+uint32_t* jump_device(int device) {
+  const std::vector<uint32_t>& h = jump_host();
+  std::lock_guard<std::mutex> lk(g_jump_mu);
+  auto it = g_jump_dev.find(device);
+  if (it != g_jump_dev.end()) return it->second;
+  uint32_t* d = nullptr;
+  HIP_CHECK(hipMalloc(&d, h.size() * sizeof(uint32_t)));
+  HIP_CHECK(hipMemcpy(d, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  g_jump_dev[device] = d;
+  return d;
+}
+
+// ThinLensCamera host side, ThinLensCamera.cuh:16-28,79-108,132-141 (host code: no fusing)
+struct Camera {
+  float position[3];   // mPosition: stored, never used (reference quirk Q1)
+  float angles[2];     // mRotationAngles, radians
+  float fov;           // mFov, radians
+  float focal, aperture;
+  float M[16];         // column-major mCameraTransformation
+
+  static float radians(float deg) { return deg * 0.01745329251994329576923690768489f; }
+
+  void transform() {                                                     // :132-141
+    float sx, cx, sy, cy;
+    rtd::sincos_spec(angles[0] * 0.5f, sx, cx);                          // glm::angleAxis
+    rtd::sincos_spec(angles[1] * 0.5f, sy, cy);
+    const float Xw = cx, Xx = 1.0f * sx, Xy = 0.0f * sx, Xz = 0.0f * sx;  // qX
+    const float Yw = cy, Yx = 0.0f * sy, Yy = 1.0f * sy, Yz = 0.0f * sy;  // qY
+    const float w = Yw * Xw - Yx * Xx - Yy * Xy - Yz * Xz;                // qY * qX
+    const float x = Yw * Xx + Yx * Xw + Yy * Xz - Yz * Xy;
+    const float y = Yw * Xy + Yy * Xw + Yz * Xx - Yx * Xz;
+    const float z = Yw * Xz + Yz * Xw + Yx * Xy - Yy * Xx;
+    const float qxx = x * x, qyy = y * y, qzz = z * z, qxz = x * z, qxy = x * y, qyz = y * z;
+    const float qwx = w * x, qwy = w * y, qwz = w * z;
+    memset(M, 0, sizeof M);                                              // glm::mat4_cast
+    M[0] = 1.0f - 2.0f * (qyy + qzz); M[1] = 2.0f * (qxy + qwz);        M[2] = 2.0f * (qxz - qwy);
+    M[4] = 2.0f * (qxy - qwz);        M[5] = 1.0f - 2.0f * (qxx + qzz); M[6] = 2.0f * (qyz + qwx);
+    M[8] = 2.0f * (qxz + qwy);        M[9] = 2.0f * (qyz - qwx);        M[10] = 1.0f - 2.0f * (qxx + qyy);
+    M[15] = 1.0f;
+  }
+  float tan_half_fov() const {                                           // :114, hoisted per launch
+    float s, c;
+    rtd::sincos_spec(fov / 2.0f, s, c);
+    return s / c;
+  }
+};
+
+struct EventPair { hipEvent_t a, b; uint32_t launches; };
+
+}  // namespace
+
+struct rt_tracer {
+  // configuration
+  int device = 0;
+  uint32_t W = 0, H = 0;            // full image
+  uint32_t row0 = 0, rows = 0;      // owned band
+  bool band_mode = false;
+  uint64_t seed = 1;
+  bool fma = true, filter = true;
+  uint32_t k_req = 0, chunk_req = 0;
+
+  // device state
+  hipStream_t stream = nullptr;
+  float4* d_render = nullptr;
+  uint32_t* d_counts = nullptr;
+  uint32_t* d_image = nullptr;
+  uint32_t* d_rng = nullptr;
+  uint32_t* h_image = nullptr;      // pinned, handed to callbacks
+  float4* d_tri = nullptr;          // v0, e1, e2 records
+  float4* d_tri_color = nullptr;
+  uint32_t n_tris = 0;
+  float4* d_spheres = nullptr;
+  uint32_t n_spheres = 0;
+
+  // camera + callbacks (guarded by state_mu; snapshotted per launch like the by-value kernel argument)
+  std::mutex state_mu;
+  Camera cam;
+  rt_callback_fn update_cb = nullptr; void* update_user = nullptr;
+  rt_callback_fn finished_cb = nullptr; void* finished_user = nullptr;
+
+  // render thread
+  std::mutex api_mu;
+  std::thread thread;
+  std::atomic<bool> stopped{false};
+  std::atomic<bool> completed{false};
+
+  // timing
+  std::mutex time_mu;
+  std::vector<EventPair> pending;
+  std::vector<EventPair> free_events;
+  double kernel_ms = 0.0;
+  uint64_t kernel_launches = 0;
+
+  std::mutex err_mu;
+  std::string last_error;
+  uint32_t last_k = 0, last_chunk = 0, last_lds = 0;
+
+  void set_error(const std::string& s) {
+    { std::lock_guard<std::mutex> lk(err_mu); last_error = s; }
+    set_global_error(s);
+  }
+  uint32_t npix() const { return W * rows; }
+  void use_device() { HIP_CHECK(hipSetDevice(device)); }
+
+  void cancel_and_join() {                                               // RayTracerImpl.cu:72-77
+    if (thread.joinable()) {
+      stopped = true;
+      thread.join();
+      stopped = false;
+    }
+  }
+
+  void release_buffers() {                                               // :317-342
+    if (d_render) (void)hipFree(d_render);
+    if (d_counts) (void)hipFree(d_counts);
+    if (d_image) (void)hipFree(d_image);
+    if (d_rng) (void)hipFree(d_rng);
+    if (h_image) (void)hipHostFree(h_image);
+    d_render = nullptr; d_counts = nullptr; d_image = nullptr; d_rng = nullptr; h_image = nullptr;
+  }
+
+  void create_states() {                                                 // random::CreateStates, Random.cu:32-52
+    uint32_t seeded[6];
+    rth::seed_state(seed, seeded);
+    const uint32_t p0 = row0 * W;                                        // subsequence of the band's first pixel
+    HIP_CHECK(rtk::launch_rng_init(d_rng, npix(), p0, seeded, jump_device(device), stream));
+  }
+
+  void create_buffers() {                                                // ctor :33-40, Resize :96-102
+    const size_t n = npix();
+    if (n == 0) throw HipFail{"image has no pixels"};
+    HIP_CHECK(hipMalloc(&d_rng, n * 6 * sizeof(uint32_t)));
+    HIP_CHECK(hipMalloc(&d_render, n * sizeof(float4)));
+    HIP_CHECK(hipMalloc(&d_counts, n * sizeof(uint32_t)));
+    HIP_CHECK(hipMalloc(&d_image, n * sizeof(uint32_t)));
+    HIP_CHECK(hipHostMalloc(&h_image, n * sizeof(uint32_t), hipHostMallocDefault));
+    // the reference leaves new buffers uninitialised until the first Trace clears them; we
+    // zero them so that reading before a Trace is defined
+    HIP_CHECK(hipMemsetAsync(d_render, 0, n * sizeof(float4), stream));
+    HIP_CHECK(hipMemsetAsync(d_counts, 0, n * sizeof(uint32_t), stream));
+    HIP_CHECK(hipMemsetAsync(d_image, 0, n * sizeof(uint32_t), stream));
+    create_states();
+    HIP_CHECK(hipStreamSynchronize(stream));
+  }
+
+  rtk::TraceParams params(uint32_t samples) {
+    rtk::TraceParams p;
+    memset(&p, 0, sizeof p);
+    Camera c;
+    { std::lock_guard<std::mutex> lk(state_mu); c = cam; }               // *mCamera by value, :221
+    p.render = d_render; p.counts = d_counts; p.rng = d_rng;
+    p.W = W; p.H = H; p.row0 = row0; p.rows = rows; p.npix = npix(); p.samples = samples;
+    for (int col = 0; col < 4; ++col)
+      for (int r = 0; r < 3; ++r) p.cam[col * 3 + r] = c.M[col * 4 + r];
+    p.half_height = c.tan_half_fov();
+    p.aspect = static_cast<float>(W) / static_cast<float>(H);            // ThinLensCamera.cuh:113
+    p.focal = c.focal; p.aperture = c.aperture;
+    p.tri = d_tri; p.tri_color = d_tri_color; p.n_tris = n_tris;
+    p.spheres = d_spheres; p.n_spheres = n_spheres;
+    p.chunk = chunk_req ? chunk_req : 1024u;
+    if (p.chunk > 3072u) p.chunk = 3072u;                                // 144 KiB of the CU's 160 KiB LDS
+    return p;
+  }
+
+  int pick_k(uint32_t samples) const {
+    if (k_req == 1 || k_req == 2 || k_req == 4) return static_cast<int>(k_req);
+    return samples >= 4 ? 4 : samples >= 2 ? 2 : 1;
+  }
+
+  EventPair take_events() {
+    std::lock_guard<std::mutex> lk(time_mu);
+    if (!free_events.empty()) { EventPair e = free_events.back(); free_events.pop_back(); return e; }
+    EventPair e{};
+    HIP_CHECK(hipEventCreate(&e.a));
+    HIP_CHECK(hipEventCreate(&e.b));
+    return e;
+  }
+
+  // RunTraceKernel, RayTracerImpl.cu:204-234, without the blocking wait
+  void enqueue_trace_launches(uint32_t iterations, uint32_t samples, bool per_iteration_sync) {
+    if (iterations == 0) return;
+    const int K = pick_k(samples);
+    for (uint32_t i = 0; i < iterations && !stopped; ++i) {
+      rtk::TraceParams p = params(samples);
+      last_k = K; last_chunk = p.chunk;
+      last_lds = (p.n_tris < p.chunk ? p.n_tris : p.chunk) * 48u;
+      EventPair e = take_events();
+      e.launches = 1;
+      HIP_CHECK(hipEventRecord(e.a, stream));
+      HIP_CHECK(rtk::launch_trace(p, fma, filter, K, stream));
+      HIP_CHECK(hipEventRecord(e.b, stream));
+      { std::lock_guard<std::mutex> lk(time_mu); pending.push_back(e); }
+      if (per_iteration_sync) { HIP_CHECK(hipEventSynchronize(e.b)); }    // :228
+    }
+  }
+
+  void drain_events() {
+    std::lock_guard<std::mutex> lk(time_mu);
+    for (EventPair& e : pending) {
+      float ms = 0.0f;
+      if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { kernel_ms += ms; kernel_launches += e.launches; }
+      free_events.push_back(e);
+    }
+    pending.clear();
+  }
+
+  void clear_accumulators() {                                            // :242-243
+    HIP_CHECK(hipMemsetAsync(d_render, 0, static_cast<size_t>(npix()) * sizeof(float4), stream));
+    HIP_CHECK(hipMemsetAsync(d_counts, 0, static_cast<size_t>(npix()) * sizeof(uint32_t), stream));
+  }
+
+  void convert_and_fetch() {                                             // RunConverterKernel :189-202 + D2H
+    HIP_CHECK(rtk::launch_convert(d_render, d_counts, d_image, npix(), stream));
+    HIP_CHECK(hipMemcpyAsync(h_image, d_image, static_cast<size_t>(npix()) * sizeof(uint32_t),
+                             hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));                             // :259,:287
+  }
+
+  // RayTracerImpl::TraceFunct, RayTracerImpl.cu:236-315 (runs on the render thread)
+  void trace_funct(uint32_t iterationCount, uint32_t samplesPerIteration, uint32_t updateInterval) {
+    try {
+      use_device();
+      clear_accumulators();
+      for (uint32_t i = 0; !stopped && i < iterationCount; ++i) {         // :246
+        enqueue_trace_launches(1, samplesPerIteration, true);            // :249
+        rt_callback_fn cb; void* user;
+        { std::lock_guard<std::mutex> lk(state_mu); cb = update_cb; user = update_user; }
+        if (cb != nullptr && i > 0 && updateInterval > 0 && i % updateInterval == 0) {   // :256
+          convert_and_fetch();
+          cb(h_image, static_cast<size_t>(npix()) * sizeof(uint32_t), user);              // :272
+        }
+      }
+      drain_events();
+      if (stopped) return;                                               // :280-284, no callback
+      convert_and_fetch();
+      completed = true;
+      rt_callback_fn cb; void* user;
+      { std::lock_guard<std::mutex> lk(state_mu); cb = finished_cb; user = finished_user; }
+      if (cb != nullptr) cb(h_image, static_cast<size_t>(npix()) * sizeof(uint32_t), user);   // :302-305
+    } catch (const HipFail& f) {                                         // :307-314 swallowed, but recorded
+      set_error(f.what);
+    } catch (...) {
+      set_error("unknown failure in the render thread");
+    }
+  }
+};
+
+namespace {
+
+size_t buffer_bytes(rt_tracer* t, int which) {
+  const size_t n = t->npix();
+  switch (which) {
+    case RT_BUF_RENDER: return n * sizeof(float4);
+    case RT_BUF_COUNTS: return n * sizeof(uint32_t);
+    case RT_BUF_IMAGE: return n * sizeof(uint32_t);
+    case RT_BUF_RNG: return n * 6 * sizeof(uint32_t);
+    default: return 0;
+  }
+}
+
+void* buffer_ptr(rt_tracer* t, int which) {
+  switch (which) {
+    case RT_BUF_RENDER: return t->d_render;
+    case RT_BUF_COUNTS: return t->d_counts;
+    case RT_BUF_IMAGE: return t->d_image;
+    case RT_BUF_RNG: return t->d_rng;
+    default: return nullptr;
+  }
+}
+
+template <class F>
+int guarded(rt_tracer* t, F&& f) {
+  try {
+    f();
+    return RT_OK;
+  } catch (const HipFail& e) {
+    if (t) t->set_error(e.what); else set_global_error(e.what);
+    return RT_ERR_HIP;
+  } catch (const std::exception& e) {
+    if (t) t->set_error(e.what()); else set_global_error(e.what());
+    return RT_ERR_STATE;
+  } catch (...) {
+    if (t) t->set_error("unknown failure"); else set_global_error("unknown failure");
+    return RT_ERR_STATE;
+  }
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  explicit DevBuf(size_t bytes) { HIP_CHECK(hipMalloc(&p, bytes ? bytes : 1)); }
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  template <class T> T* as() { return static_cast<T*>(p); }
+};
+
+int require_device(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    set_global_error(fmt("no HIP device available (%s); librt_mi355x has no CPU fallback",
+                         e == hipSuccess ? "device count 0" : hipGetErrorString(e)));
+    return RT_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= n) {
+    set_global_error(fmt("device %d out of range (%d devices)", device, n));
+    return RT_ERR_INVALID;
+  }
+  return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_version(void) { return "rt_mi355x 0.1 (gfx950)"; }
+
+int rt_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* rt_last_error(void) {
+  static thread_local std::string copy;
+  std::lock_guard<std::mutex> lk(g_err_mu);
+  copy = g_last_error;
+  return copy.c_str();
+}
+
+const char* rt_tracer_last_error(rt_tracer* t) {
+  static thread_local std::string copy;
+  if (!t) return rt_last_error();
+  std::lock_guard<std::mutex> lk(t->err_mu);
+  copy = t->last_error;
+  return copy.c_str();
+}
+
+int rt_tracer_create_ex(const uint32_t imageSize[2], const float cameraPosition[3],
+                        const float cameraAngles[2], float fov, float focalLength, float aperture,
+                        const rt_options* options, rt_tracer** out) {
+  if (!out) return RT_ERR_INVALID;
+  *out = nullptr;
+  if (!imageSize || !cameraAngles || imageSize[0] == 0 || imageSize[1] == 0) {
+    set_global_error("rt_tracer_create: invalid image size or camera angles");
+    return RT_ERR_INVALID;
+  }
+  rt_options opt;
+  memset(&opt, 0, sizeof opt);
+  opt.use_time_seed = 1;                                                 // Random.cu:45 by default
+  if (options) {
+    const size_t n = options->struct_size < sizeof(opt) ? options->struct_size : sizeof(opt);
+    if (n < 8) { set_global_error("rt_options.struct_size not set"); return RT_ERR_INVALID; }
+    opt.use_time_seed = 0;
+    memcpy(&opt, options, n);
+  }
+  int rc = require_device(opt.device);
+  if (rc != RT_OK) return rc;
+
+  rt_tracer* t = new rt_tracer();
+  t->device = opt.device;
+  t->W = imageSize[0];
+  if (opt.full_height) {
+    t->band_mode = true;
+    t->H = opt.full_height; t->row0 = opt.row_begin; t->rows = imageSize[1];
+    if (static_cast<uint64_t>(t->row0) + t->rows > t->H) {
+      delete t;
+      set_global_error("row band exceeds full_height");
+      return RT_ERR_INVALID;
+    }
+  } else {
+    t->H = imageSize[1]; t->row0 = 0; t->rows = imageSize[1];
+  }
+  t->seed = opt.use_time_seed ? static_cast<uint64_t>(static_cast<uint32_t>(time(nullptr))) : opt.seed;
+  t->fma = opt.math_mode != RT_MATH_STRICT;
+  t->filter = (opt.flags & RT_FLAG_NO_FILTER) == 0;
+  t->k_req = opt.samples_in_flight;
+  t->chunk_req = opt.lds_chunk;
+  Camera& c = t->cam;
+  for (int i = 0; i < 3; ++i) c.position[i] = cameraPosition ? cameraPosition[i] : 0.0f;
+  c.angles[0] = cameraAngles[0]; c.angles[1] = cameraAngles[1];
+  c.fov = Camera::radians(fov);                                          // ThinLensCamera.cuh:23
+  c.focal = focalLength; c.aperture = aperture;
+  c.transform();                                                         // :27
+  rc = guarded(t, [&] {
+    t->use_device();
+    HIP_CHECK(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+    t->create_buffers();
+  });
+  if (rc != RT_OK) {
+    // the reference's ctor logs and carries on with null buffers (RayTracerImpl.cu:42-45);
+    // a C ABI can do better: report, release, hand back nothing.
+    std::string why = t->last_error;
+    t->release_buffers();
+    if (t->stream) (void)hipStreamDestroy(t->stream);
+    delete t;
+    set_global_error("rt_tracer_create: " + why);
+    return rc;
+  }
+  *out = t;
+  return RT_OK;
+}
+
+int rt_tracer_create(const uint32_t imageSize[2], const float cameraPosition[3],
+                     const float cameraAngles[2], float fov, float focalLength, float aperture,
+                     rt_tracer** out) {
+  return rt_tracer_create_ex(imageSize, cameraPosition, cameraAngles, fov, focalLength, aperture,
+                             nullptr, out);
+}
+
+void rt_tracer_destroy(rt_tracer* t) {                                   // RayTracerImpl.cu:48-67
+  if (!t) return;
+  t->stopped = true;
+  if (t->thread.joinable()) t->thread.join();
+  (void)hipSetDevice(t->device);
+  if (t->stream) (void)hipStreamSynchronize(t->stream);
+  t->drain_events();
+  for (EventPair& e : t->free_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  if (t->d_tri) (void)hipFree(t->d_tri);
+  if (t->d_tri_color) (void)hipFree(t->d_tri_color);
+  if (t->d_spheres) (void)hipFree(t->d_spheres);
+  t->release_buffers();
+  if (t->stream) (void)hipStreamDestroy(t->stream);
+  delete t;
+}
+
+int rt_tracer_trace(rt_tracer* t, uint32_t iterationCount, uint32_t samplesPerIteration,
+                    uint32_t updateInterval) {
+  if (!t) return RT_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(t->api_mu);
+  return guarded(t, [&] {
+    t->cancel_and_join();                                                // :72-77
+    t->completed = false;
+    t->thread = std::thread(&rt_tracer::trace_funct, t, iterationCount, samplesPerIteration,
+                            updateInterval);                             // :80-85
+  });
+}
+
+void rt_tracer_stop(rt_tracer* t) {                                      // :89-92
+  if (t) t->stopped = true;
+}
+
+int rt_tracer_wait(rt_tracer* t) {
+  if (!t) return 0;
+  std::lock_guard<std::mutex> lk(t->api_mu);
+  if (t->thread.joinable()) t->thread.join();
+  t->stopped = false;
+  return t->completed ? 1 : 0;
+}
+
+int rt_tracer_resize(rt_tracer* t, const uint32_t size[2]) {             // :94-103
+  if (!t || !size || size[0] == 0 || size[1] == 0) return RT_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(t->api_mu);
+  return guarded(t, [&] {
+    t->cancel_and_join();
+    t->use_device();
+    HIP_CHECK(hipStreamSynchronize(t->stream));
+    t->release_buffers();
+    t->W = size[0];
+    if (t->band_mode) {
+      if (static_cast<uint64_t>(t->row0) + size[1] > t->H) throw HipFail{"row band exceeds full_height"};
+      t->rows = size[1];
+    } else {
+      t->H = size[1]; t->rows = size[1];
+    }
+    t->create_buffers();
+  });
+}
+
+void rt_tracer_set_camera_parameters(rt_tracer* t, float fov, float focalLength, float aperture) {
+  if (!t) return;                                                        // :105-112
+  std::lock_guard<std::mutex> lk(t->state_mu);
+  t->cam.fov = Camera::radians(fov);
+  t->cam.focal = focalLength;
+  t->cam.aperture = aperture;
+}
+
+void rt_tracer_rotate_camera(rt_tracer* t, const float angles[2]) {      // :114-117
+  if (!t || !angles) return;
+  std::lock_guard<std::mutex> lk(t->state_mu);
+  t->cam.angles[0] += angles[0];                                         // ThinLensCamera.cuh:104-108
+  t->cam.angles[1] += angles[1];
+  t->cam.transform();
+}
+
+int rt_tracer_upload_scene(rt_tracer* t, const rt_float4* hostData, size_t count) {
+  if (!t) return RT_ERR_INVALID;
+  if (!hostData || count < 3 || count % 3 != 0) {                        // :121-125
+    t->set_error(fmt("UploadScene got invalid triangle list. Size = %zu", count));
+    return RT_ERR_INVALID;
+  }
+  std::lock_guard<std::mutex> lk(t->api_mu);
+  return guarded(t, [&] {
+    t->cancel_and_join();
+    t->use_device();
+    HIP_CHECK(hipStreamSynchronize(t->stream));
+    if (t->d_tri) { (void)hipFree(t->d_tri); t->d_tri = nullptr; }       // :128-137
+    if (t->d_tri_color) { (void)hipFree(t->d_tri_color); t->d_tri_color = nullptr; }
+    t->n_tris = 0;
+    const uint32_t n = static_cast<uint32_t>(count / 3);                 // :139
+    DevBuf verts(count * sizeof(float4));
+    HIP_CHECK(hipMalloc(&t->d_tri, count * sizeof(float4)));
+    HIP_CHECK(hipMalloc(&t->d_tri_color, static_cast<size_t>(n) * sizeof(float4)));
+    HIP_CHECK(hipMemcpyAsync(verts.p, hostData, count * sizeof(float4), hipMemcpyHostToDevice, t->stream));
+    HIP_CHECK(rtk::launch_prep_triangles(t->fma, verts.as<float4>(), n, t->d_tri, t->d_tri_color, t->stream));
+    HIP_CHECK(hipStreamSynchronize(t->stream));
+    t->n_tris = n;
+  });
+}
+
+int rt_tracer_upload_spheres(rt_tracer* t, const rt_float4* spheres, size_t count) {
+  if (!t || (count && !spheres)) return RT_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(t->api_mu);
+  return guarded(t, [&] {
+    t->cancel_and_join();
+    t->use_device();
+    HIP_CHECK(hipStreamSynchronize(t->stream));
+    if (t->d_spheres) { (void)hipFree(t->d_spheres); t->d_spheres = nullptr; }
+    t->n_spheres = 0;
+    if (count == 0) return;
+    HIP_CHECK(hipMalloc(&t->d_spheres, count * sizeof(float4)));
+    HIP_CHECK(hipMemcpy(t->d_spheres, spheres, count * sizeof(float4), hipMemcpyHostToDevice));
+    t->n_spheres = static_cast<uint32_t>(count);
+  });
+}
+
+void rt_tracer_set_update_callback(rt_tracer* t, rt_callback_fn fn, void* user) {     // :179-182
+  if (!t) return;
+  std::lock_guard<std::mutex> lk(t->state_mu);
+  t->update_cb = fn; t->update_user = user;
+}
+
+void rt_tracer_set_finished_callback(rt_tracer* t, rt_callback_fn fn, void* user) {   // :184-187
+  if (!t) return;
+  std::lock_guard<std::mutex> lk(t->state_mu);
+  t->finished_cb = fn; t->finished_user = user;
+}
+
+int rt_tracer_set_seed(rt_tracer* t, uint64_t seed) {
+  if (!t) return RT_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(t->api_mu);
+  return guarded(t, [&] {
+    t->cancel_and_join();
+    t->use_device();
+    t->seed = seed;
+    t->create_states();
+    HIP_CHECK(hipStreamSynchronize(t->stream));
+  });
+}
+
+int rt_tracer_trace_enqueue(rt_tracer* t, uint32_t iterationCount, uint32_t samplesPerIteration) {
+  if (!t) return RT_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(t->api_mu);
+  return guarded(t, [&] {
+    t->cancel_and_join();
+    t->use_device();
+    t->clear_accumulators();
+    t->enqueue_trace_launches(iterationCount, samplesPerIteration, false);
+    HIP_CHECK(rtk::launch_convert(t->d_render, t->d_counts, t->d_image, t->npix(), t->stream));
+  });
+}
+
+int rt_tracer_sync(rt_tracer* t) {
+  if (!t) return RT_ERR_INVALID;
+  return guarded(t, [&] {
+    t->use_device();
+    HIP_CHECK(hipStreamSynchronize(t->stream));
+    t->drain_events();
+  });
+}
+
+int rt_tracer_kernel_time(rt_tracer* t, double* total_ms, uint64_t* launches, int reset_after) {
+  if (!t) return RT_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(t->time_mu);
+  if (total_ms) *total_ms = t->kernel_ms;
+  if (launches) *launches = t->kernel_launches;
+  if (reset_after) { t->kernel_ms = 0.0; t->kernel_launches = 0; }
+  return RT_OK;
+}
+
+size_t rt_tracer_buffer_bytes(rt_tracer* t, int which) { return t ? buffer_bytes(t, which) : 0; }
+void* rt_tracer_device_pointer(rt_tracer* t, int which) { return t ? buffer_ptr(t, which) : nullptr; }
+
+int rt_tracer_read_buffer(rt_tracer* t, int which, void* dst, size_t bytes) {
+  if (!t || !dst || buffer_ptr(t, which) == nullptr || bytes > buffer_bytes(t, which)) return RT_ERR_INVALID;
+  return guarded(t, [&] {
+    t->use_device();
+    HIP_CHECK(hipStreamSynchronize(t->stream));
+    HIP_CHECK(hipMemcpy(dst, buffer_ptr(t, which), bytes, hipMemcpyDeviceToHost));
+  });
+}
+
+int rt_tracer_copy_buffer_to_device(rt_tracer* t, int which, void* dst_device, size_t bytes) {
+  if (!t || !dst_device || buffer_ptr(t, which) == nullptr || bytes > buffer_bytes(t, which)) return RT_ERR_INVALID;
+  return guarded(t, [&] {
+    t->use_device();
+    HIP_CHECK(hipMemcpyAsync(dst_device, buffer_ptr(t, which), bytes, hipMemcpyDeviceToDevice, t->stream));
+    HIP_CHECK(hipStreamSynchronize(t->stream));
+  });
+}
+
+int rt_tracer_info(rt_tracer* t, uint32_t out[8]) {
+  if (!t || !out) return RT_ERR_INVALID;
+  out[0] = t->last_k; out[1] = t->last_chunk; out[2] = t->last_lds;
+  out[3] = (t->W + 31) / 32; out[4] = (t->rows + 7) / 8;
+  out[5] = t->n_tris; out[6] = t->n_spheres; out[7] = static_cast<uint32_t>(t->device);
+  return RT_OK;
+}
+
+// ---- single-function device harnesses -----------------------------------------------------
+
+int rt_dbg_hit_triangle(int device, uint32_t math_mode, uint32_t n, const float* rays, const float* tris,
+                        int eps_mode, int32_t* hit, float* tuv, float* normal, float* point) {
+  int rc = require_device(device);
+  if (rc != RT_OK) return rc;
+  return guarded(nullptr, [&] {
+    HIP_CHECK(hipSetDevice(device));
+    DevBuf dr(n * 6 * sizeof(float)), dt(n * 9 * sizeof(float)), dh(n * sizeof(int)),
+        duv(n * 3 * sizeof(float)), dn(n * 3 * sizeof(float)), dp(n * 3 * sizeof(float));
+    HIP_CHECK(hipMemcpy(dr.p, rays, n * 6 * sizeof(float), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dt.p, tris, n * 9 * sizeof(float), hipMemcpyHostToDevice));
+    HIP_CHECK(rtk::launch_dbg_hit_triangle(math_mode != RT_MATH_STRICT, n, dr.as<float>(), dt.as<float>(),
+                                           eps_mode, dh.as<int>(), duv.as<float>(), dn.as<float>(),
+                                           dp.as<float>(), nullptr));
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(hit, dh.p, n * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(tuv, duv.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(normal, dn.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(point, dp.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+  });
+}
+
+int rt_dbg_sincos(int device, uint32_t n, const float* x, float* s, float* c) {
+  int rc = require_device(device);
+  if (rc != RT_OK) return rc;
+  return guarded(nullptr, [&] {
+    HIP_CHECK(hipSetDevice(device));
+    DevBuf dx(n * sizeof(float)), ds(n * sizeof(float)), dc(n * sizeof(float));
+    HIP_CHECK(hipMemcpy(dx.p, x, n * sizeof(float), hipMemcpyHostToDevice));
+    HIP_CHECK(rtk::launch_dbg_sincos(n, dx.as<float>(), ds.as<float>(), dc.as<float>(), nullptr));
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(s, ds.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(c, dc.p, n * sizeof(float), hipMemcpyDeviceToHost));
+  });
+}
+
+int rt_dbg_uniform(int device, uint32_t n, uint32_t m, uint32_t* states, float* out) {
+  int rc = require_device(device);
+  if (rc != RT_OK) return rc;
+  return guarded(nullptr, [&] {
+    HIP_CHECK(hipSetDevice(device));
+    DevBuf ds(n * 6 * sizeof(uint32_t)), dout(static_cast<size_t>(n) * m * sizeof(float));
+    HIP_CHECK(hipMemcpy(ds.p, states, n * 6 * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_CHECK(rtk::launch_dbg_uniform(n, m, ds.as<uint32_t>(), dout.as<float>(), nullptr));
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(states, ds.p, n * 6 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(out, dout.p, static_cast<size_t>(n) * m * sizeof(float), hipMemcpyDeviceToHost));
+  });
+}
+
+int rt_dbg_get_ray(rt_tracer* t, uint32_t n, const uint32_t* pixels, uint32_t* states, float* rays) {
+  if (!t) return RT_ERR_INVALID;
+  return guarded(t, [&] {
+    t->use_device();
+    rtk::TraceParams p = t->params(1);
+    DevBuf dpix(n * 2 * sizeof(uint32_t)), ds(n * 6 * sizeof(uint32_t)), dr(n * 6 * sizeof(float));
+    HIP_CHECK(hipMemcpy(dpix.p, pixels, n * 2 * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(ds.p, states, n * 6 * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_CHECK(rtk::launch_dbg_get_ray(t->fma, p, n, dpix.as<uint32_t>(), ds.as<uint32_t>(), dr.as<float>(),
+                                      t->stream));
+    HIP_CHECK(hipStreamSynchronize(t->stream));
+    HIP_CHECK(hipMemcpy(states, ds.p, n * 6 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(rays, dr.p, n * 6 * sizeof(float), hipMemcpyDeviceToHost));
+  });
+}
+
+void rt_dbg_rng_init_host(uint64_t seed, uint64_t subsequence, uint32_t state[6]) {
+  rth::init_state(jump_host(), seed, subsequence & 0xffffffffull, state);
+}
+
+}  // extern "C"
