@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""bench.py -- Mray/s of the trace path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one complete Trace pass of the hot path on device-resident buffers: clear the
+accumulators, ONE trace-kernel launch of `samples` spp over the rank's rows, the BGRA8
+conversion and -- for N > 1 -- the RCCL gather of the finished tiles to rank 0
+(RayTracerImpl.cu:236-315 without the GUI hand-off).  Workload at N=1: BASELINE.json
+configs[2] = C3 (Cornell-box 32 triangles, thin-lens DoF, 1920x1080, 16 spp), the
+configuration the metric is quoted on.  For N > 1 the image grows to 1920 x (1080*N) and
+every rank owns one 1080-row band: per-GPU work is fixed ("weak"), no data-path collective
+except the tile gather the north star names.
+
+Prints ONE JSON line on rank 0 with `roofline` (HBM, algorithmic bytes / live HIP-event
+kernel time) and `cpu_baseline` (the oracle -- a scalar CPU port -- timed on this box's
+cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak (spec)
+RNG_STATE_BYTES = 24           # persisted per pixel: d + v[5] (the reference's curandState_t is 48)
+
+
+def algorithmic_bytes(width, rows, n_tris, n_spheres):
+    """per launch, W*H*(2*R + 32) + 48*N_tri + 16*N_sph; R = 24 here.
+    32 = render-buffer RMW 12+12 + sample-count RMW 4+4."""
+    return width * rows * (2 * RNG_STATE_BYTES + 32) + 48 * n_tris + 16 * n_spheres
+
+
+def cpu_baseline(cfg, tris, spheres, rows, threads):
+    """The oracle (CPU port of the reference kernel) on a bounded sample: `rows` centred
+    rows of the same frame, one launch of cfg['samples'] spp, `threads` host threads.
+    RNG-state creation is outside the timed region, as on the GPU."""
+    from oracle import oracle_py as orc
+    H = cfg["height"]
+    row0 = (H - rows) // 2
+    o = orc.OracleTracer(cfg["width"], H, cfg["angles"], cfg["fov"], cfg["focal"], cfg["aperture"],
+                         seed=cfg["seed"], row0=row0, rows=rows, contract=orc.FMA, nthreads=threads)
+    if tris.shape[0]:
+        o.upload_scene(tris)
+    if spheres.shape[0]:
+        o.upload_spheres(spheres)
+    t0 = time.perf_counter()
+    o.launch(cfg["samples"])
+    dt = time.perf_counter() - t0
+    rays = cfg["width"] * rows * cfg["samples"]
+    return {"value": round(rays / dt / 1e6, 3), "unit": "Mray/s", "cores": threads, "kind": "port",
+            "sample": "%d centred rows of the %dx%d frame (rows %d..%d), 1 launch x %d spp, %.1f s wall; "
+                      "oracle/oracle.c gcc -O2 -ffp-contract=off, scalar, row-threaded"
+                      % (rows, cfg["width"], H, row0, row0 + rows - 1, cfg["samples"], dt)}, o, row0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4"])
+    ap.add_argument("--cpu-rows", type=int, default=-1, help="rows of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--samples-in-flight", type=int, default=0)
+    ap.add_argument("--lds-chunk", type=int, default=0)
+    args = ap.parse_args()
+
+    import raytracertest_amd as R
+    from raytracertest_amd import scenes
+    from raytracertest_amd.dist import RowBandJob
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+        args.gpus = world
+
+    cfg = dict(scenes.CONFIGS[args.config])
+    tris, spheres = scenes.scene_for(args.config)
+    n_tris = tris.shape[0] // 3
+
+    job = RowBandJob(cfg, tris, spheres, world=world, rank=rank, local_rank=local_rank, weak=True,
+                     samples_in_flight=args.samples_in_flight, lds_chunk=args.lds_chunk)
+    for _ in range(args.warmup):
+        job.step()
+    job.finish()
+    job.tracer.KernelTime(reset=True)
+
+    job.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        job.step()
+    job.finish()
+    job.barrier()
+    elapsed = job.max_over_ranks(time.perf_counter() - t0)
+
+    kernel_ms, launches = job.tracer.KernelTime(reset=True)
+    rays_per_step = cfg["width"] * cfg["height"] * cfg["samples"] * cfg["iterations"] * world
+    value = rays_per_step * args.steps / elapsed / 1e6
+
+    if rank == 0:
+        avg_kernel_s = kernel_ms / max(launches, 1) / 1e3
+        b_alg = algorithmic_bytes(cfg["width"], cfg["height"], n_tris, spheres.shape[0])
+        achieved = b_alg / avg_kernel_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(args.config, {}).get("bytes_per_launch")
+        tests_per_launch = cfg["width"] * cfg["height"] * cfg["samples"] * n_tris
+        out = {
+            "metric": "Mray/s at %dx%dx%dspp" % (cfg["width"], cfg["height"], cfg["samples"]),
+            "value": round(value, 2), "unit": "Mray/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": {"C2": "C2: 1 sphere, pinhole, 512x512, 1 spp",
+                                    "C3": "C3: Cornell-box 32 triangles, thin-lens DoF, 1920x1080, 16 spp",
+                                    "C4": "C4: 10k random triangles, 3840x2160, 64 spp"}[args.config],
+                       "image": "%dx%d per GPU (row band of a %dx%d frame)" % (
+                           cfg["width"], cfg["height"], cfg["width"], cfg["height"] * world),
+                       "triangles": n_tris, "spheres": int(spheres.shape[0]), "samples_per_launch": cfg["samples"],
+                       "launch": job.tracer.Info(), "math_mode": "fma", "rng_seed": cfg["seed"],
+                       "sharding": "row bands, RCCL gather of BGRA8 tiles to rank 0" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "kernel": "trace_kernel", "kernel_us": round(avg_kernel_s * 1e6, 2),
+                         "algorithmic_bytes_per_launch": b_alg,
+                         "note": "path is fp32-VALU-bound by construction (SURVEY 0.5): see valu"},
+            "valu": {"tests_per_s": round(tests_per_launch / avg_kernel_s, 1),
+                     "kernel_Mray_s": round(cfg["width"] * cfg["height"] * cfg["samples"] / avg_kernel_s / 1e6, 2),
+                     "flop_upper_bound_per_test": 52,
+                     "frac_of_fp32_peak_upper_bound": round(tests_per_launch * 52 / avg_kernel_s / 1e12 / VALU_PEAK_TFLOPS, 4)},
+        }
+        if world == 1 and args.cpu_rows != 0:
+            threads = len(os.sched_getaffinity(0))
+            rows = args.cpu_rows if args.cpu_rows > 0 else min(cfg["height"], {"C2": 512, "C3": 1080, "C4": 8}[args.config])
+            base, o, row0 = cpu_baseline(cfg, tris, spheres, rows, threads)
+            out["cpu_baseline"] = base
+        print(json.dumps(out), flush=True)
+    job.close()
+
+
+if __name__ == "__main__":
+    main()
