@@ -10,13 +10,18 @@ accumulators, ONE trace-kernel launch of `samples` spp over the rank's rows, the
 conversion and -- for N > 1 -- the RCCL gather of the finished tiles to rank 0
 (RayTracerImpl.cu:236-315 without the GUI hand-off).  Workload at N=1: BASELINE.json
 configs[2] = C3 (Cornell-box 32 triangles, thin-lens DoF, 1920x1080, 16 spp), the
-configuration the metric is quoted on.  For N > 1 the image grows to 1920 x (1080*N) and
+configuration the metric is quoted on.  For N > 1 the frame grows to 1920 x (1080*N) and
 every rank owns one 1080-row band: per-GPU work is fixed ("weak"), no data-path collective
 except the tile gather the north star names.
 
-Prints ONE JSON line on rank 0 with `roofline` (HBM, algorithmic bytes / live HIP-event
-kernel time) and `cpu_baseline` (the oracle -- a scalar CPU port -- timed on this box's
-cores on a bounded sample).
+Prints ONE JSON line on rank 0 with
+  roofline      HBM: algorithmic bytes per launch / live HIP-event kernel time vs 8 TB/s
+                (contractual bound; the path is VALU-bound by construction)
+  valu          the binding bound: algorithmic fp32 flops (by the reference's exit points,
+                counted by an instrumented launch) vs the 157.3 TFLOP/s spec peak and vs
+                the lane-FMA rate this device sustains (calibrated live)
+  cpu_baseline  the oracle (scalar CPU port of the reference kernel) timed on this box's
+                cores on a bounded sample of the same workload
 """
 import argparse
 import json
@@ -28,17 +33,29 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak (spec)
 RNG_STATE_BYTES = 24           # persisted per pixel: d + v[5] (the reference's curandState_t is 48)
+FLOP_BY_EXIT = (20, 30, 46, 52)   # culled at det / rejected at u / at v / full
+FLOP_PER_RAY_SETUP = 100          # ray generation + shading, per ray
 
 
 def algorithmic_bytes(width, rows, n_tris, n_spheres):
     """per launch, W*H*(2*R + 32) + 48*N_tri + 16*N_sph; R = 24 here.
     32 = render-buffer RMW 12+12 + sample-count RMW 4+4."""
     return width * rows * (2 * RNG_STATE_BYTES + 32) + 48 * n_tris + 16 * n_spheres
+
+
+def host_threads():
+    """Threads for the CPU baseline: the box's CPU share (cgroup quota if any, else 16)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("RT_BENCH_CPU_THREADS", "16"))))
 
 
 def cpu_baseline(cfg, tris, spheres, rows, threads):
@@ -55,13 +72,18 @@ def cpu_baseline(cfg, tris, spheres, rows, threads):
     if spheres.shape[0]:
         o.upload_spheres(spheres)
     t0 = time.perf_counter()
-    o.launch(cfg["samples"])
+    o.launch(cfg["samples"])                     # sizing pass (also warms the caches), not reported
+    probe = time.perf_counter() - t0
+    launches = max(1, min(64, int(round(20.0 / max(probe * threads, 1e-3)))))   # ~20 core-seconds
+    t0 = time.perf_counter()
+    for _ in range(launches):
+        o.launch(cfg["samples"])
     dt = time.perf_counter() - t0
-    rays = cfg["width"] * rows * cfg["samples"]
+    rays = cfg["width"] * rows * cfg["samples"] * launches
     return {"value": round(rays / dt / 1e6, 3), "unit": "Mray/s", "cores": threads, "kind": "port",
-            "sample": "%d centred rows of the %dx%d frame (rows %d..%d), 1 launch x %d spp, %.1f s wall; "
-                      "oracle/oracle.c gcc -O2 -ffp-contract=off, scalar, row-threaded"
-                      % (rows, cfg["width"], H, row0, row0 + rows - 1, cfg["samples"], dt)}, o, row0
+            "sample": "%d centred rows of the %dx%d frame (rows %d..%d), %d launches x %d spp = %d rays, %.1f s wall "
+                      "(%.0f core-seconds); oracle/oracle.c, gcc -O2 -ffp-contract=off, scalar, row-threaded"
+                      % (rows, cfg["width"], H, row0, row0 + rows - 1, launches, cfg["samples"], rays, dt, dt * threads)}
 
 
 def main():
@@ -71,12 +93,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4"])
     ap.add_argument("--cpu-rows", type=int, default=-1, help="rows of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-valu", action="store_true", help="skip the instrumented launch + VALU calibration")
     ap.add_argument("--samples-in-flight", type=int, default=0)
     ap.add_argument("--lds-chunk", type=int, default=0)
     args = ap.parse_args()
 
     import raytracertest_amd as R
-    from raytracertest_amd import scenes
+    from raytracertest_amd import api, scenes
     from raytracertest_amd.dist import RowBandJob
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -108,8 +131,8 @@ def main():
     elapsed = job.max_over_ranks(time.perf_counter() - t0)
 
     kernel_ms, launches = job.tracer.KernelTime(reset=True)
-    rays_per_step = cfg["width"] * cfg["height"] * cfg["samples"] * cfg["iterations"] * world
-    value = rays_per_step * args.steps / elapsed / 1e6
+    rays_per_gpu = cfg["width"] * cfg["height"] * cfg["samples"] * cfg["iterations"]
+    value = rays_per_gpu * world * args.steps / elapsed / 1e6
 
     if rank == 0:
         avg_kernel_s = kernel_ms / max(launches, 1) / 1e3
@@ -119,7 +142,6 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get(args.config, {}).get("bytes_per_launch")
-        tests_per_launch = cfg["width"] * cfg["height"] * cfg["samples"] * n_tris
         out = {
             "metric": "Mray/s at %dx%dx%dspp" % (cfg["width"], cfg["height"], cfg["samples"]),
             "value": round(value, 2), "unit": "Mray/s", "n_gpus": world, "steps": args.steps,
@@ -137,18 +159,39 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": "trace_kernel", "kernel_us": round(avg_kernel_s * 1e6, 2),
+                         "kernel_Mray_s": round(rays_per_gpu / avg_kernel_s / 1e6, 2),
                          "algorithmic_bytes_per_launch": b_alg,
-                         "note": "path is fp32-VALU-bound by construction (SURVEY 0.5): see valu"},
-            "valu": {"tests_per_s": round(tests_per_launch / avg_kernel_s, 1),
-                     "kernel_Mray_s": round(cfg["width"] * cfg["height"] * cfg["samples"] / avg_kernel_s / 1e6, 2),
-                     "flop_upper_bound_per_test": 52,
-                     "frac_of_fp32_peak_upper_bound": round(tests_per_launch * 52 / avg_kernel_s / 1e12 / VALU_PEAK_TFLOPS, 4)},
+                         "note": "contractual bound; the path is fp32-VALU-bound by construction "
+                                 "(SURVEY.md 0.5, BASELINE.md 2): see valu"},
         }
+        if not args.no_valu:
+            # instrumented launch (reference-order path) on a scratch tracer: exit points per test
+            g = R.RayTracer((cfg["width"], cfg["height"]), (0, 0, 0), cfg["angles"], cfg["fov"], cfg["focal"],
+                            cfg["aperture"], seed=cfg["seed"], device=local_rank, no_filter=True)
+            if tris.shape[0]:
+                g.UploadScene(tris)
+            if spheres.shape[0]:
+                g.UploadSpheres(spheres)
+            st_samples = cfg["samples"] if args.config != "C4" else 4
+            st = g.TraceStats(st_samples)
+            g.close()
+            exits = [st["exit_det"], st["exit_u"], st["exit_v"], st["exit_hit"]]
+            scale = cfg["samples"] / st_samples
+            flop = scale * sum(f * e for f, e in zip(FLOP_BY_EXIT, exits)) + FLOP_PER_RAY_SETUP * rays_per_gpu
+            lane_fma, ghz = api.dbg_valu_peak(local_rank)
+            tf = flop / avg_kernel_s / 1e12
+            out["valu"] = {"bound": "fp32 VALU", "achieved": round(tf, 2), "peak": VALU_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": round(tf / VALU_PEAK_TFLOPS, 4),
+                           "attainable": round(2 * lane_fma / 1e12, 2), "frac_attainable": round(tf / (2 * lane_fma / 1e12), 4),
+                           "clock_ghz_under_load": round(ghz, 3),
+                           "tests_per_s": round(scale * sum(exits) / avg_kernel_s, 1),
+                           "exit_fractions": [round(e / max(sum(exits), 1), 4) for e in exits],
+                           "algorithmic_flop_per_launch": int(flop),
+                           "note": "flops per test by the reference's exit point (20/30/46/52, FMA = 2) + 100 per ray; "
+                                   "attainable = 2 x lane-FMA/s of an 8-chain fma loop at 8 waves/SIMD on this device"}
         if world == 1 and args.cpu_rows != 0:
-            threads = len(os.sched_getaffinity(0))
             rows = args.cpu_rows if args.cpu_rows > 0 else min(cfg["height"], {"C2": 512, "C3": 1080, "C4": 8}[args.config])
-            base, o, row0 = cpu_baseline(cfg, tris, spheres, rows, threads)
-            out["cpu_baseline"] = base
+            out["cpu_baseline"] = cpu_baseline(cfg, tris, spheres, rows, host_threads())
         print(json.dumps(out), flush=True)
     job.close()
 

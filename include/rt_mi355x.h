@@ -122,6 +122,14 @@ int  rt_tracer_sync(rt_tracer* t);
 /* Sum of the trace-kernel durations (HIP events on the tracer's stream) and number of
  * trace-kernel launches since the last reset; reset_after != 0 clears both. */
 int  rt_tracer_kernel_time(rt_tracer* t, double* total_ms, uint64_t* launches, int reset_after);
+/* One instrumented launch (clear + trace of `samples` spp with counters; not a timed path).
+ * Lane-level counters need RT_FLAG_NO_FILTER (reference-order path), wave-level ones the
+ * default filtered path:
+ *   out[0..3] ray-triangle tests by the reference's exit point: culled at det
+ *             (Kernels.cuh:42), rejected at u (:51), rejected at v (:58), full hit (:63);
+ *   out[4..7] (wave, triangle) pairs skipped by the __ballot early-outs after stage A
+ *             (culling), B (u), C (v), and pairs that reached the exact stage D. */
+int  rt_tracer_trace_stats(rt_tracer* t, uint32_t samples, uint64_t out[8]);
 /* Copy one of the tracer's device buffers to host memory / to another device pointer. */
 int  rt_tracer_read_buffer(rt_tracer* t, int which, void* dst, size_t bytes);
 int  rt_tracer_copy_buffer_to_device(rt_tracer* t, int which, void* dst_device, size_t bytes);
@@ -144,6 +152,9 @@ int rt_dbg_hit_triangle(int device, uint32_t math_mode, uint32_t n, const float*
                         const float* tris, int eps_mode, int32_t* hit, float* tuv, float* normal,
                         float* point);
 int rt_dbg_sincos(int device, uint32_t n, const float* x, float* s, float* c);
+/* fp32 VALU calibration on this device: attainable lane-FMA/s (8 fma chains per lane,
+ * 8 waves per SIMD, every CU) and the shader clock held meanwhile.  Measurement aid only. */
+int rt_dbg_valu_peak(int device, double* lane_fma_per_s, double* clock_ghz);
 /* states n*6 {d,v0..v4} advanced in place, out n*m uniforms in (0,1] */
 int rt_dbg_uniform(int device, uint32_t n, uint32_t m, uint32_t* states, float* out);
 /* thin-lens rays of the tracer's current camera for n (x, y) pixels with given RNG states */

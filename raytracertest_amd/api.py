@@ -13,7 +13,8 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "lib", "librt_mi355x.so")
+# RT_MI355X_LIB selects another build of the same library (kernel A/B experiments only)
+_LIB_PATH = os.environ.get("RT_MI355X_LIB") or os.path.join(_HERE, "lib", "librt_mi355x.so")
 
 MATH_FMA, MATH_STRICT = 0, 1
 FLAG_NO_FILTER = 1
@@ -25,11 +26,11 @@ ABI_SYMBOLS = [
     "rt_tracer_stop", "rt_tracer_resize", "rt_tracer_set_camera_parameters",
     "rt_tracer_rotate_camera", "rt_tracer_upload_scene", "rt_tracer_set_update_callback",
     "rt_tracer_set_finished_callback", "rt_tracer_wait", "rt_tracer_set_seed",
-    "rt_tracer_upload_spheres", "rt_tracer_trace_enqueue", "rt_tracer_sync",
+    "rt_tracer_upload_spheres", "rt_tracer_trace_enqueue", "rt_tracer_sync", "rt_tracer_trace_stats",
     "rt_tracer_kernel_time", "rt_tracer_read_buffer", "rt_tracer_copy_buffer_to_device",
     "rt_tracer_device_pointer", "rt_tracer_buffer_bytes", "rt_tracer_info",
     "rt_tracer_last_error", "rt_last_error", "rt_device_count", "rt_version",
-    "rt_dbg_hit_triangle", "rt_dbg_sincos", "rt_dbg_uniform", "rt_dbg_get_ray",
+    "rt_dbg_hit_triangle", "rt_dbg_sincos", "rt_dbg_valu_peak", "rt_dbg_uniform", "rt_dbg_get_ray",
     "rt_dbg_rng_init_host",
 ]
 
@@ -89,6 +90,7 @@ def load_library():
         L.rt_tracer_upload_spheres.argtypes = [vp, vp, C.c_size_t]
         L.rt_tracer_trace_enqueue.argtypes = [vp, C.c_uint32, C.c_uint32]
         L.rt_tracer_sync.argtypes = [vp]
+        L.rt_tracer_trace_stats.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64)]
         L.rt_tracer_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
         L.rt_tracer_read_buffer.argtypes = [vp, C.c_int, vp, C.c_size_t]
         L.rt_tracer_copy_buffer_to_device.argtypes = [vp, C.c_int, vp, C.c_size_t]
@@ -106,6 +108,7 @@ def load_library():
                                           C.POINTER(C.c_int32), f32p, f32p, f32p]
         L.rt_dbg_sincos.argtypes = [C.c_int, C.c_uint32, f32p, f32p, f32p]
         L.rt_dbg_uniform.argtypes = [C.c_int, C.c_uint32, C.c_uint32, u32p, f32p]
+        L.rt_dbg_valu_peak.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.rt_dbg_get_ray.argtypes = [vp, C.c_uint32, u32p, u32p, f32p]
         L.rt_dbg_rng_init_host.argtypes = [C.c_uint64, C.c_uint64, u32p]
         L.rt_dbg_rng_init_host.restype = None
@@ -205,6 +208,14 @@ class RayTracer:
 
     def Sync(self):
         self._check(self._lib.rt_tracer_sync(self._h))
+
+    def TraceStats(self, samples):
+        """One instrumented launch; see rt_tracer_trace_stats in include/rt_mi355x.h."""
+        out = (C.c_uint64 * 8)()
+        self._check(self._lib.rt_tracer_trace_stats(self._h, samples, out))
+        v = [int(x) for x in out]
+        return {"exit_det": v[0], "exit_u": v[1], "exit_v": v[2], "exit_hit": v[3],
+                "skip_a": v[4], "skip_b": v[5], "skip_c": v[6], "reach_d": v[7]}
 
     def KernelTime(self, reset=True):
         ms, n = C.c_double(), C.c_uint64()
@@ -312,6 +323,16 @@ def dbg_sincos(x, device=0):
     if rc != 0:
         raise RtError("rt_dbg_sincos failed (%d): %s" % (rc, L.rt_last_error().decode()))
     return s, c
+
+
+def dbg_valu_peak(device=0):
+    """(attainable lane-FMA per second, shader clock GHz) measured on `device`."""
+    L = load_library()
+    r, g = C.c_double(), C.c_double()
+    rc = L.rt_dbg_valu_peak(device, C.byref(r), C.byref(g))
+    if rc != 0:
+        raise RtError("rt_dbg_valu_peak failed (%d): %s" % (rc, L.rt_last_error().decode()))
+    return r.value, g.value
 
 
 def dbg_uniform(states, m, device=0):

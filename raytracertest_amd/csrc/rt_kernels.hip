@@ -71,10 +71,15 @@ __global__ __launch_bounds__(256) void rng_init_kernel(uint32_t* __restrict__ rn
 // Per-triangle invariants.  e1 = v1 - v0 and e2 = v2 - v0 are the same fp32 subtractions
 // HitTriangle performs per ray (Kernels.cuh:37-38); colour = abs(normalize(cross(e1,e2)))
 // is the shade of a hit (Kernels.cuh:97-99), a function of the triangle only.
+// Record layout (36 bytes per triangle, what the trace kernel stages into LDS):
+//   tri_a[2i]   = (e2.x, e2.y, e2.z, e1.x)      stage A reads tri_a[2i], tri_a[2i+1]
+//   tri_a[2i+1] = (e1.y, e1.z, v0.x, v0.y)      (two ds_read_b128, wave-uniform)
+//   tri_b[i]    = v0.z                          stage B adds one ds_read_b32
 // ------------------------------------------------------------------------------------
 template <bool FMA>
 __global__ __launch_bounds__(256) void prep_triangles_kernel(const float4* __restrict__ verts, uint32_t n,
-                                                              float4* __restrict__ rec,
+                                                              float4* __restrict__ tri_a,
+                                                              float* __restrict__ tri_b,
                                                               float4* __restrict__ color) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
@@ -82,9 +87,9 @@ __global__ __launch_bounds__(256) void prep_triangles_kernel(const float4* __res
   const V3 v0 = {a.x, a.y, a.z};
   const V3 e1 = rtd::sub({b.x, b.y, b.z}, v0);
   const V3 e2 = rtd::sub({c.x, c.y, c.z}, v0);
-  rec[3 * i + 0] = make_float4(v0.x, v0.y, v0.z, 0.0f);
-  rec[3 * i + 1] = make_float4(e1.x, e1.y, e1.z, 0.0f);
-  rec[3 * i + 2] = make_float4(e2.x, e2.y, e2.z, 0.0f);
+  tri_a[2 * i + 0] = make_float4(e2.x, e2.y, e2.z, e1.x);
+  tri_a[2 * i + 1] = make_float4(e1.y, e1.z, v0.x, v0.y);
+  tri_b[i] = v0.z;
   const V3 nn = Math<FMA>::normalize(Math<FMA>::cross(e1, e2));
   color[i] = make_float4(rtd::absf(nn.x), rtd::absf(nn.y), rtd::absf(nn.z), 0.0f);
 }
@@ -92,21 +97,26 @@ __global__ __launch_bounds__(256) void prep_triangles_kernel(const float4* __res
 // ------------------------------------------------------------------------------------
 // Exact HitTriangle in the reference's operation order (Kernels.cuh:29-65) on a
 // precomputed (v0, e1, e2).  Used by the unfiltered trace path and the dbg harness.
+// `stage` reports the exit point: 0 culled at det, 1 rejected at u, 2 rejected at v, 3 hit.
 // ------------------------------------------------------------------------------------
 template <bool FMA>
 __device__ __forceinline__ bool hit_triangle_exact(V3 o, V3 d, V3 v0, V3 e1, V3 e2, float eps,
-                                                   float& t, float& u, float& v) {
+                                                   float& t, float& u, float& v, int& stage) {
   using M = Math<FMA>;
+  stage = 0;
   const V3 pv = M::cross(d, e2);                       // :39
   const float det = M::dot(e1, pv);                    // :40
   if (det < eps) return false;                         // :42
+  stage = 1;
   const float inv = 1.0f / det;                        // :47
   const V3 tv = rtd::sub(o, v0);                       // :49
   u = M::dot(tv, pv) * inv;                            // :50
   if (u < 0.0f || u > 1.0f) return false;              // :51
+  stage = 2;
   const V3 qv = M::cross(tv, e1);                      // :56
   v = M::dot(d, qv) * inv;                             // :57
   if (v < 0.0f || u + v > 1.0f) return false;          // :58
+  stage = 3;
   t = M::dot(e2, qv) * inv;                            // :63
   return true;
 }
@@ -146,9 +156,9 @@ __device__ __forceinline__ void pinhole(const TraceParams& p, uint32_t px, uint3
   d = M::normalize(rtd::sub(pw, o));                                              // :127-128
 }
 
-// ThinLensCamera::GetRay, ThinLensCamera.cuh:30-52; (po, pd) is the pixel's pinhole ray
+// ThinLensCamera::GetRay, ThinLensCamera.cuh:30-52; pd is the pixel's pinhole direction
 template <bool FMA>
-__device__ __forceinline__ void get_ray(const TraceParams& p, V3 po, V3 pd, Rng& rng, V3& o, V3& d) {
+__device__ __forceinline__ void get_ray(const TraceParams& p, V3 pd, Rng& rng, V3& o, V3& d) {
   using M = Math<FMA>;
   float dx, dy;
   rtd::uniform_on_disk(rng, dx, dy);                                              // :41
@@ -156,32 +166,38 @@ __device__ __forceinline__ void get_ray(const TraceParams& p, V3 po, V3 pd, Rng&
   const V3 off = {dx * p.aperture, dy * p.aperture, 0.0f};
   const V3 focal = {M::madd1(p.focal, pd.x, pos.x), M::madd1(p.focal, pd.y, pos.y),
                     M::madd1(p.focal, pd.z, pos.z)};                              // :44
-  (void)po;
   o = rtd::add(pos, off);                                                         // :47
   d = M::normalize(rtd::sub(focal, o));                                           // :50
 }
 
-// Conservative rejections (FILTER): never reject a ray the exact path would keep.
-//   u = fl(U*inv), inv = fl(1/det), det >= 1e-10:
-//     U < -1e-12 and det < 1e12  =>  |U*inv| >= ~1e-24 (normal) and negative  => u < 0
-//     U > fl(det*1.00001)        =>  U/det > 1 + 9e-6  => u > 1
-//   same for v; u + v > 1 is certain when U, V >= 0 and fl(U+V) > fl(det*1.0001).
-//   NaN/inf operands make every comparison false -> not rejected -> exact path decides.
-__device__ __forceinline__ bool reject_u(float U, float det) {
-  return (U < -1e-12f && det < 1e12f) || (U > det * 1.00001f);
-}
-__device__ __forceinline__ bool reject_v(float U, float V, float det) {
-  return (V < -1e-12f && det < 1e12f) || (U >= 0.0f && V >= 0.0f && (U + V) > det * 1.0001f);
-}
+// ------------------------------------------------------------------------------------
+// The trace kernel.  grid = (ceil(W/32), ceil(rows/8)), block = 256 threads,
+// dynamic LDS = min(n_tris, chunk) * 36 bytes.
+//
+// FILTER: three wave-uniform early-outs per triangle, decided with __ballot on
+// CONSERVATIVE per-ray rejections -- a ray is only ever dropped when the reference's own
+// test is certain to miss, and a triangle is skipped only when every ray of the wave is
+// dropped; whenever any ray survives, stage D evaluates the reference's exact test
+// (division included) for all lanes from the values already computed.  With
+// u = fl(U*inv), v = fl(V*inv), inv = fl(1/det), det >= 1e-10 (not culled):
+//   U > fl(det*1.0001)            => U/det > 1.00009            => u > 1      (miss, :51)
+//   U < fl(det*-1e-6)             => U/det < -0.99e-6 (normal)  => u < 0      (miss, :51)
+//   V < fl(det*-1e-6)             =>                               v < 0      (miss, :58)
+//   U+V > fl(det*1.0001), with U,V >= -1e-6 det (not dropped above)
+//                                 => u+v > 1.0001 - 4e-6 - roundoff > 1       (miss, :58)
+// NaN/inf operands make every comparison false: the ray is kept and stage D decides.
+// tests/test_gpu_parity.py::test_filter_off_equals_filter_on checks FILTER against the
+// plain reference-order path bit for bit.
+// ------------------------------------------------------------------------------------
+#define RT_EPS 0.0000000001f
+#ifndef RT_TRACE_MIN_WAVES
+#define RT_TRACE_MIN_WAVES 1     // __launch_bounds__ 2nd argument: waves per SIMD the allocator must allow
+#endif
 
-// ------------------------------------------------------------------------------------
-// The trace kernel.  grid = (ceil(W/32), ceil(rows/8)), block = 256, dynamic LDS =
-// min(n_tris, chunk) * 48 bytes.
-// ------------------------------------------------------------------------------------
-template <bool FMA, int K, bool FILTER>
-__global__ __launch_bounds__(256) void trace_kernel(const TraceParams p) {
+template <bool FMA, int K, bool FILTER, bool STATS>
+__global__ __launch_bounds__(256, RT_TRACE_MIN_WAVES) void trace_kernel(const TraceParams p) {
   using M = Math<FMA>;
-  extern __shared__ float4 s_tri[];
+  extern __shared__ float4 s_mem[];
 
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t px = blockIdx.x * 32u + wave * 8u + (lane & 7u);
@@ -202,13 +218,19 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceParams p) {
   pinhole<FMA>(p, cxp, p.row0 + cyp, po, pd);
 
   const uint32_t n = p.n_tris;
+  const uint32_t cap = n < p.chunk ? n : p.chunk;                  // triangles resident in LDS
+  float4* const sA = s_mem;                                        // 2 float4 per triangle
+  float* const sB = reinterpret_cast<float*>(s_mem + 2u * cap);    // 1 float per triangle
   const bool single_chunk = n <= p.chunk;
   if (single_chunk) {
-    for (uint32_t i = threadIdx.x; i < 3u * n; i += 256u) s_tri[i] = p.tri[i];
+    for (uint32_t i = threadIdx.x; i < 2u * n; i += 256u) sA[i] = p.tri_a[i];
+    for (uint32_t i = threadIdx.x; i < n; i += 256u) sB[i] = p.tri_b[i];
     __syncthreads();
   }
 
   float ax = 0.0f, ay = 0.0f, az = 0.0f;                           // accu, :133
+  unsigned long long st_exit[4] = {0, 0, 0, 0};                    // STATS: lane-tests by exit point
+  unsigned long long st_skip[4] = {0, 0, 0, 0};                    // STATS: wave-triangles skipped after A/B/C, reaching D
 
   for (uint32_t s0 = 0; s0 < p.samples; s0 += K) {                 // :134, K samples per pass
     V3 o[K], d[K];
@@ -216,7 +238,7 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceParams p) {
     int best_i[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      if (s0 + k < p.samples) get_ray<FMA>(p, po, pd, rng, o[k], d[k]);    // :136
+      if (s0 + k < p.samples) get_ray<FMA>(p, pd, rng, o[k], d[k]);   // :136
       else { o[k] = po; d[k] = pd; }                               // padding ray, result discarded
       best_t[k] = -FLT_MAX;                                        // :73
       best_i[k] = -1;
@@ -226,78 +248,92 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceParams p) {
       const uint32_t cn = (n - c0 < p.chunk) ? n - c0 : p.chunk;
       if (!single_chunk) {
         __syncthreads();                                           // everyone done with the previous chunk
-        for (uint32_t i = threadIdx.x; i < 3u * cn; i += 256u) s_tri[i] = p.tri[3u * c0 + i];
+        for (uint32_t i = threadIdx.x; i < 2u * cn; i += 256u) sA[i] = p.tri_a[2u * c0 + i];
+        for (uint32_t i = threadIdx.x; i < cn; i += 256u) sB[i] = p.tri_b[c0 + i];
         __syncthreads();
       }
       for (uint32_t j = 0; j < cn; ++j) {                          // :75, ascending order
-        const float4 A = s_tri[3u * j + 0], B = s_tri[3u * j + 1], C = s_tri[3u * j + 2];
-        const V3 v0 = {A.x, A.y, A.z}, e1 = {B.x, B.y, B.z}, e2 = {C.x, C.y, C.z};
+        const float4 A0 = sA[2u * j + 0], A1 = sA[2u * j + 1];
+        const V3 e2 = {A0.x, A0.y, A0.z}, e1 = {A0.w, A1.x, A1.y};
         const int tri_index = static_cast<int>(c0 + j);
 
         if constexpr (!FILTER) {
+          const V3 v0 = {A1.z, A1.w, sB[j]};
 #pragma unroll
           for (int k = 0; k < K; ++k) {
             float t = 0.0f, u = 0.0f, v = 0.0f;
-            if (hit_triangle_exact<FMA>(o[k], d[k], v0, e1, e2, 0.0000000001f, t, u, v) &&
-                best_t[k] < t) {                                   // :84
+            int stage;
+            const bool h = hit_triangle_exact<FMA>(o[k], d[k], v0, e1, e2, RT_EPS, t, u, v, stage);
+            if (h && best_t[k] < t) {                              // :84
               best_t[k] = t;
               best_i[k] = tri_index;
             }
+            if constexpr (STATS) {
+              const bool counted = inside && (s0 + k < p.samples);
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                st_exit[e] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(counted && stage == e));
+            }
           }
         } else {
-          // stage A: pv, det, culling (:39-45)
+          // stage A: pv = cross(dir, e2), det = dot(e1, pv), culling (:39-45)
           V3 pv[K];
           float det[K];
-          bool live[K];
-          bool any_live = false;
+          unsigned long long mk[K];
+          unsigned long long live = 0ull;
 #pragma unroll
           for (int k = 0; k < K; ++k) {
             pv[k] = M::cross(d[k], e2);
             det[k] = M::dot(e1, pv[k]);
-            live[k] = !(det[k] < 0.0000000001f);
-            any_live |= live[k];
+            mk[k] = __builtin_amdgcn_ballot_w64(!(det[k] < RT_EPS));
+            live |= mk[k];
           }
-          if (__builtin_amdgcn_ballot_w64(any_live) == 0ull) continue;     // whole wave culled
+          if (live == 0ull) { if constexpr (STATS) st_skip[0]++; continue; }   // whole wave culled
 
-          // stage B: U = dot(tv, pv) (:49-50), conservative u rejection
+          // stage B: U = dot(origin - v0, pv) (:49-50), conservative u rejection
+          const V3 v0 = {A1.z, A1.w, sB[j]};
           V3 tv[K];
-          float U[K];
-          any_live = false;
+          float U[K], thi[K], tlo[K];
+          live = 0ull;
 #pragma unroll
           for (int k = 0; k < K; ++k) {
             tv[k] = rtd::sub(o[k], v0);
             U[k] = M::dot(tv[k], pv[k]);
-            live[k] = live[k] && !reject_u(U[k], det[k]);
-            any_live |= live[k];
+            thi[k] = det[k] * 1.0001f;
+            tlo[k] = det[k] * -1e-6f;
+            mk[k] &= __builtin_amdgcn_ballot_w64(!(U[k] > thi[k])) &
+                     __builtin_amdgcn_ballot_w64(!(U[k] < tlo[k]));
+            live |= mk[k];
           }
-          if (__builtin_amdgcn_ballot_w64(any_live) == 0ull) continue;
+          if (live == 0ull) { if constexpr (STATS) st_skip[1]++; continue; }
 
-          // stage C: V = dot(dir, qv) (:56-57), conservative v rejection
+          // stage C: V = dot(dir, cross(tv, e1)) (:56-57), conservative v rejection
           V3 qv[K];
           float V[K];
-          any_live = false;
+          live = 0ull;
 #pragma unroll
           for (int k = 0; k < K; ++k) {
             qv[k] = M::cross(tv[k], e1);
             V[k] = M::dot(d[k], qv[k]);
-            live[k] = live[k] && !reject_v(U[k], V[k], det[k]);
-            any_live |= live[k];
+            mk[k] &= __builtin_amdgcn_ballot_w64(!(V[k] < tlo[k])) &
+                     __builtin_amdgcn_ballot_w64(!((U[k] + V[k]) > thi[k]));
+            live |= mk[k];
           }
-          if (__builtin_amdgcn_ballot_w64(any_live) == 0ull) continue;
+          if (live == 0ull) { if constexpr (STATS) st_skip[2]++; continue; }
+          if constexpr (STATS) st_skip[3]++;
 
-          // stage D: the reference's exact tests on the survivors (:47-63, :84)
+          // stage D: the reference's exact tests (:42-63, :84) wherever a ray may hit
 #pragma unroll
           for (int k = 0; k < K; ++k) {
-            if (live[k]) {
-              const float inv = 1.0f / det[k];
-              const float u = U[k] * inv;
-              const float v = V[k] * inv;
-              const bool miss = (u < 0.0f || u > 1.0f) || (v < 0.0f || u + v > 1.0f);
-              const float t = M::dot(e2, qv[k]) * inv;
-              if (!miss && best_t[k] < t) {
-                best_t[k] = t;
-                best_i[k] = tri_index;
-              }
+            if (mk[k] != 0ull) {
+              const float inv = 1.0f / det[k];                     // :47
+              const float u = U[k] * inv;                          // :50
+              const float v = V[k] * inv;                          // :57
+              const float t = M::dot(e2, qv[k]) * inv;             // :63
+              const bool miss = (det[k] < RT_EPS) | (u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f);
+              const bool upd = (!miss) & (best_t[k] < t);          // :84
+              best_t[k] = upd ? t : best_t[k];
+              best_i[k] = upd ? tri_index : best_i[k];
             }
           }
         }
@@ -357,6 +393,15 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceParams p) {
     p.rng[4 * static_cast<size_t>(p.npix) + pix] = rng.v3;
     p.rng[5 * static_cast<size_t>(p.npix) + pix] = rng.v4;
   }
+  if constexpr (STATS) {
+    if (lane == 0 && p.stats != nullptr) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        atomicAdd(p.stats + e, st_exit[e]);
+        atomicAdd(p.stats + 4 + e, st_skip[e]);
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -390,7 +435,8 @@ __global__ void dbg_hit_triangle_kernel(uint32_t n, const float* __restrict__ ra
   const V3 a = {q[0], q[1], q[2]}, b = {q[3], q[4], q[5]}, c = {q[6], q[7], q[8]};
   const V3 e1 = rtd::sub(b, a), e2 = rtd::sub(c, a);
   float t = 0.0f, u = 0.0f, v = 0.0f;
-  const bool h = hit_triangle_exact<FMA>(o, d, a, e1, e2, eps_mode ? FLT_EPSILON : 0.0000000001f, t, u, v);
+  int stage;
+  const bool h = hit_triangle_exact<FMA>(o, d, a, e1, e2, eps_mode ? FLT_EPSILON : 0.0000000001f, t, u, v, stage);
   hit[i] = h ? 1 : 0;
   tuv[3 * i + 0] = t; tuv[3 * i + 1] = u; tuv[3 * i + 2] = v;
   const V3 nn = M::normalize(M::cross(e1, e2));
@@ -430,10 +476,37 @@ __global__ void dbg_get_ray_kernel(const TraceParams p, uint32_t n, const uint32
   Rng r = {s[0], s[1], s[2], s[3], s[4], s[5]};
   V3 po, pd, o, d;
   pinhole<FMA>(p, pixels[2 * i], pixels[2 * i + 1], po, pd);
-  get_ray<FMA>(p, po, pd, r, o, d);
+  get_ray<FMA>(p, pd, r, o, d);
   float* out = rays + 6 * static_cast<size_t>(i);
   out[0] = o.x; out[1] = o.y; out[2] = o.z; out[3] = d.x; out[4] = d.y; out[5] = d.z;
   s[0] = r.d; s[1] = r.v0; s[2] = r.v1; s[3] = r.v2; s[4] = r.v3; s[5] = r.v4;
+}
+
+// fp32 VALU calibration: 8 independent fma chains per lane, 16x unrolled.  Measures the
+// attainable lane-FMA rate of THIS device under load (the honest denominator of the trace
+// kernel's VALU roofline) and the clock it holds (s_memtime ticks / 100 MHz realtime).
+__global__ __launch_bounds__(256) void dbg_valu_peak_kernel(float* __restrict__ out, int iters,
+                                                             unsigned long long* __restrict__ clk) {
+  float a[8];
+  const float x = 1.0000001f + threadIdx.x * 1e-9f, y = 1e-7f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) a[c] = static_cast<float>(c + threadIdx.x);
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  for (int i = 0; i < iters; i += 16) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) a[c] = __builtin_fmaf(a[c], x, y);
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  float s = 0.0f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) s += a[c];
+  out[blockIdx.x * 256u + threadIdx.x] = s;
+  if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
 }
 
 // ------------------------------------------------------------------------------------
@@ -448,30 +521,39 @@ hipError_t launch_rng_init(uint32_t* rng, uint32_t npix, uint32_t p0, const uint
   return hipGetLastError();
 }
 
-hipError_t launch_prep_triangles(bool fma, const float4* verts, uint32_t n, float4* rec, float4* color,
-                                 hipStream_t st) {
+hipError_t launch_prep_triangles(bool fma, const float4* verts, uint32_t n, float4* tri_a, float* tri_b,
+                                 float4* color, hipStream_t st) {
   if (n == 0) return hipSuccess;
-  if (fma) hipLaunchKernelGGL(prep_triangles_kernel<true>, dim3(cdiv(n, 256)), dim3(256), 0, st, verts, n, rec, color);
-  else hipLaunchKernelGGL(prep_triangles_kernel<false>, dim3(cdiv(n, 256)), dim3(256), 0, st, verts, n, rec, color);
+  if (fma) hipLaunchKernelGGL(prep_triangles_kernel<true>, dim3(cdiv(n, 256)), dim3(256), 0, st, verts, n, tri_a, tri_b, color);
+  else hipLaunchKernelGGL(prep_triangles_kernel<false>, dim3(cdiv(n, 256)), dim3(256), 0, st, verts, n, tri_a, tri_b, color);
   return hipGetLastError();
 }
 
-template <bool FMA, bool FILTER>
+template <bool FMA, bool FILTER, bool STATS>
 static void launch_trace_k(const TraceParams& p, int K, dim3 grid, size_t lds, hipStream_t st) {
   switch (K) {
-    case 1: hipLaunchKernelGGL((trace_kernel<FMA, 1, FILTER>), grid, dim3(256), lds, st, p); break;
-    case 2: hipLaunchKernelGGL((trace_kernel<FMA, 2, FILTER>), grid, dim3(256), lds, st, p); break;
-    default: hipLaunchKernelGGL((trace_kernel<FMA, 4, FILTER>), grid, dim3(256), lds, st, p); break;
+    case 1: hipLaunchKernelGGL((trace_kernel<FMA, 1, FILTER, STATS>), grid, dim3(256), lds, st, p); break;
+    case 2: hipLaunchKernelGGL((trace_kernel<FMA, 2, FILTER, STATS>), grid, dim3(256), lds, st, p); break;
+    default: hipLaunchKernelGGL((trace_kernel<FMA, 4, FILTER, STATS>), grid, dim3(256), lds, st, p); break;
   }
+}
+
+uint32_t trace_lds_bytes(const TraceParams& p) {
+  const uint32_t staged = p.n_tris < p.chunk ? p.n_tris : p.chunk;
+  return staged * 36u;
 }
 
 hipError_t launch_trace(const TraceParams& p, bool fma, bool filter, int K, hipStream_t st) {
   if (p.rows == 0 || p.W == 0 || p.samples == 0) return hipSuccess;
   const dim3 grid(cdiv(p.W, 32), cdiv(p.rows, 8));
-  const uint32_t staged = p.n_tris < p.chunk ? p.n_tris : p.chunk;
-  const size_t lds = static_cast<size_t>(staged) * 48u;
-  if (fma) { if (filter) launch_trace_k<true, true>(p, K, grid, lds, st); else launch_trace_k<true, false>(p, K, grid, lds, st); }
-  else { if (filter) launch_trace_k<false, true>(p, K, grid, lds, st); else launch_trace_k<false, false>(p, K, grid, lds, st); }
+  const size_t lds = trace_lds_bytes(p);
+  if (p.stats != nullptr) {          // instrumented build of the same kernel (not the timed path)
+    if (fma) { if (filter) launch_trace_k<true, true, true>(p, K, grid, lds, st); else launch_trace_k<true, false, true>(p, K, grid, lds, st); }
+    else { if (filter) launch_trace_k<false, true, true>(p, K, grid, lds, st); else launch_trace_k<false, false, true>(p, K, grid, lds, st); }
+  } else {
+    if (fma) { if (filter) launch_trace_k<true, true, false>(p, K, grid, lds, st); else launch_trace_k<true, false, false>(p, K, grid, lds, st); }
+    else { if (filter) launch_trace_k<false, true, false>(p, K, grid, lds, st); else launch_trace_k<false, false, false>(p, K, grid, lds, st); }
+  }
   return hipGetLastError();
 }
 
@@ -487,6 +569,11 @@ hipError_t launch_dbg_hit_triangle(bool fma, uint32_t n, const float* rays, cons
   if (n == 0) return hipSuccess;
   if (fma) hipLaunchKernelGGL(dbg_hit_triangle_kernel<true>, dim3(cdiv(n, 64)), dim3(64), 0, st, n, rays, tris, eps_mode, hit, tuv, normal, point);
   else hipLaunchKernelGGL(dbg_hit_triangle_kernel<false>, dim3(cdiv(n, 64)), dim3(64), 0, st, n, rays, tris, eps_mode, hit, tuv, normal, point);
+  return hipGetLastError();
+}
+
+hipError_t launch_dbg_valu_peak(uint32_t blocks, int iters, float* out, unsigned long long* clk, hipStream_t st) {
+  hipLaunchKernelGGL(dbg_valu_peak_kernel, dim3(blocks), dim3(256), 0, st, out, iters, clk);
   return hipGetLastError();
 }
 

@@ -18,24 +18,28 @@ struct TraceParams {
   uint32_t  samples;   // sampleCount of this launch
   float     cam[12];   // mCameraTransformation: xyz of the 4 columns
   float     half_height, aspect, focal, aperture;
-  const float4* tri;        // 3 float4 per triangle: v0, e1 = v1-v0, e2 = v2-v0
+  const float4* tri_a;      // 2 float4 per triangle: (e2.xyz, e1.x), (e1.yz, v0.xy); e1 = v1-v0, e2 = v2-v0
+  const float*  tri_b;      // 1 float per triangle: v0.z
   const float4* tri_color;  // abs(normalize(cross(e1,e2)))
   uint32_t  n_tris;
   const float4* spheres;    // centre xyz, radius (build-defined extension)
   uint32_t  n_spheres;
   uint32_t  chunk;          // triangles staged into LDS at a time
+  unsigned long long* stats; // null in the product path; 8 counters for the instrumented launch
 };
 
 hipError_t launch_rng_init(uint32_t* rng, uint32_t npix, uint32_t p0, const uint32_t seeded[6],
                            const uint32_t* jump, hipStream_t st);
-hipError_t launch_prep_triangles(bool fma, const float4* verts, uint32_t n, float4* rec, float4* color,
-                                 hipStream_t st);
+hipError_t launch_prep_triangles(bool fma, const float4* verts, uint32_t n, float4* tri_a, float* tri_b,
+                                 float4* color, hipStream_t st);
+uint32_t trace_lds_bytes(const TraceParams& p);
 hipError_t launch_trace(const TraceParams& p, bool fma, bool filter, int K, hipStream_t st);
 hipError_t launch_convert(const float4* render, const uint32_t* counts, uint32_t* image, uint32_t npix,
                           hipStream_t st);
 
 hipError_t launch_dbg_hit_triangle(bool fma, uint32_t n, const float* rays, const float* tris, int eps_mode,
                                    int* hit, float* tuv, float* normal, float* point, hipStream_t st);
+hipError_t launch_dbg_valu_peak(uint32_t blocks, int iters, float* out, unsigned long long* clk, hipStream_t st);
 hipError_t launch_dbg_sincos(uint32_t n, const float* x, float* s, float* c, hipStream_t st);
 hipError_t launch_dbg_uniform(uint32_t n, uint32_t m, uint32_t* states, float* out, hipStream_t st);
 hipError_t launch_dbg_get_ray(bool fma, const TraceParams& p, uint32_t n, const uint32_t* pixels,

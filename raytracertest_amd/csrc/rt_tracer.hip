@@ -129,7 +129,8 @@ struct rt_tracer {
   uint32_t* d_image = nullptr;
   uint32_t* d_rng = nullptr;
   uint32_t* h_image = nullptr;      // pinned, handed to callbacks
-  float4* d_tri = nullptr;          // v0, e1, e2 records
+  float4* d_tri = nullptr;          // (e2.xyz,e1.x),(e1.yz,v0.xy) records
+  float* d_tri_b = nullptr;         // v0.z
   float4* d_tri_color = nullptr;
   uint32_t n_tris = 0;
   float4* d_spheres = nullptr;
@@ -218,10 +219,11 @@ struct rt_tracer {
     p.half_height = c.tan_half_fov();
     p.aspect = static_cast<float>(W) / static_cast<float>(H);            // ThinLensCamera.cuh:113
     p.focal = c.focal; p.aperture = c.aperture;
-    p.tri = d_tri; p.tri_color = d_tri_color; p.n_tris = n_tris;
+    p.tri_a = d_tri; p.tri_b = d_tri_b; p.tri_color = d_tri_color; p.n_tris = n_tris;
+    p.stats = nullptr;
     p.spheres = d_spheres; p.n_spheres = n_spheres;
     p.chunk = chunk_req ? chunk_req : 1024u;
-    if (p.chunk > 3072u) p.chunk = 3072u;                                // 144 KiB of the CU's 160 KiB LDS
+    if (p.chunk > 4096u) p.chunk = 4096u;                                // 144 KiB of the CU's 160 KiB LDS
     return p;
   }
 
@@ -246,7 +248,7 @@ struct rt_tracer {
     for (uint32_t i = 0; i < iterations && !stopped; ++i) {
       rtk::TraceParams p = params(samples);
       last_k = K; last_chunk = p.chunk;
-      last_lds = (p.n_tris < p.chunk ? p.n_tris : p.chunk) * 48u;
+      last_lds = rtk::trace_lds_bytes(p);
       EventPair e = take_events();
       e.launches = 1;
       HIP_CHECK(hipEventRecord(e.a, stream));
@@ -478,6 +480,7 @@ void rt_tracer_destroy(rt_tracer* t) {                                   // RayT
   t->drain_events();
   for (EventPair& e : t->free_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (t->d_tri) (void)hipFree(t->d_tri);
+  if (t->d_tri_b) (void)hipFree(t->d_tri_b);
   if (t->d_tri_color) (void)hipFree(t->d_tri_color);
   if (t->d_spheres) (void)hipFree(t->d_spheres);
   t->release_buffers();
@@ -556,14 +559,17 @@ int rt_tracer_upload_scene(rt_tracer* t, const rt_float4* hostData, size_t count
     t->use_device();
     HIP_CHECK(hipStreamSynchronize(t->stream));
     if (t->d_tri) { (void)hipFree(t->d_tri); t->d_tri = nullptr; }       // :128-137
+    if (t->d_tri_b) { (void)hipFree(t->d_tri_b); t->d_tri_b = nullptr; }
     if (t->d_tri_color) { (void)hipFree(t->d_tri_color); t->d_tri_color = nullptr; }
     t->n_tris = 0;
     const uint32_t n = static_cast<uint32_t>(count / 3);                 // :139
     DevBuf verts(count * sizeof(float4));
-    HIP_CHECK(hipMalloc(&t->d_tri, count * sizeof(float4)));
+    HIP_CHECK(hipMalloc(&t->d_tri, static_cast<size_t>(n) * 2 * sizeof(float4)));
+    HIP_CHECK(hipMalloc(&t->d_tri_b, static_cast<size_t>(n) * sizeof(float)));
     HIP_CHECK(hipMalloc(&t->d_tri_color, static_cast<size_t>(n) * sizeof(float4)));
     HIP_CHECK(hipMemcpyAsync(verts.p, hostData, count * sizeof(float4), hipMemcpyHostToDevice, t->stream));
-    HIP_CHECK(rtk::launch_prep_triangles(t->fma, verts.as<float4>(), n, t->d_tri, t->d_tri_color, t->stream));
+    HIP_CHECK(rtk::launch_prep_triangles(t->fma, verts.as<float4>(), n, t->d_tri, t->d_tri_b,
+                                         t->d_tri_color, t->stream));
     HIP_CHECK(hipStreamSynchronize(t->stream));
     t->n_tris = n;
   });
@@ -618,6 +624,23 @@ int rt_tracer_trace_enqueue(rt_tracer* t, uint32_t iterationCount, uint32_t samp
     t->clear_accumulators();
     t->enqueue_trace_launches(iterationCount, samplesPerIteration, false);
     HIP_CHECK(rtk::launch_convert(t->d_render, t->d_counts, t->d_image, t->npix(), t->stream));
+  });
+}
+
+int rt_tracer_trace_stats(rt_tracer* t, uint32_t samples, uint64_t out[8]) {
+  if (!t || !out) return RT_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(t->api_mu);
+  return guarded(t, [&] {
+    t->cancel_and_join();
+    t->use_device();
+    DevBuf counters(8 * sizeof(unsigned long long));
+    HIP_CHECK(hipMemsetAsync(counters.p, 0, 8 * sizeof(unsigned long long), t->stream));
+    t->clear_accumulators();
+    rtk::TraceParams p = t->params(samples);
+    p.stats = counters.as<unsigned long long>();
+    HIP_CHECK(rtk::launch_trace(p, t->fma, t->filter, t->pick_k(samples), t->stream));
+    HIP_CHECK(hipStreamSynchronize(t->stream));
+    HIP_CHECK(hipMemcpy(out, counters.p, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   });
 }
 
@@ -688,6 +711,34 @@ int rt_dbg_hit_triangle(int device, uint32_t math_mode, uint32_t n, const float*
     HIP_CHECK(hipMemcpy(tuv, duv.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(normal, dn.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(point, dp.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+  });
+}
+
+int rt_dbg_valu_peak(int device, double* lane_fma_per_s, double* clock_ghz) {
+  int rc = require_device(device);
+  if (rc != RT_OK) return rc;
+  return guarded(nullptr, [&] {
+    HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    const uint32_t blocks = static_cast<uint32_t>(prop.multiProcessorCount) * 8u;   // 8 waves per SIMD
+    const int iters = 20000;
+    DevBuf out(static_cast<size_t>(blocks) * 256 * sizeof(float)), clk(2 * sizeof(unsigned long long));
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    HIP_CHECK(rtk::launch_dbg_valu_peak(blocks, iters, out.as<float>(), clk.as<unsigned long long>(), nullptr));
+    HIP_CHECK(hipEventRecord(e0, nullptr));
+    HIP_CHECK(rtk::launch_dbg_valu_peak(blocks, iters, out.as<float>(), clk.as<unsigned long long>(), nullptr));
+    HIP_CHECK(hipEventRecord(e1, nullptr));
+    HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long c[2];
+    HIP_CHECK(hipMemcpy(c, clk.p, sizeof c, hipMemcpyDeviceToHost));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (lane_fma_per_s) *lane_fma_per_s = static_cast<double>(blocks) * 256.0 * iters * 8.0 / (ms * 1e-3);
+    if (clock_ghz) *clock_ghz = c[1] ? static_cast<double>(c[0]) / static_cast<double>(c[1]) * 0.1 : 0.0;
   });
 }
 

@@ -156,7 +156,7 @@ def test_filter_off_equals_filter_on(rt, orc):
 
 def test_lds_chunking_invariance(rt, orc):
     g, o = run_pair(rt, orc, 40, 24, scene("rand300"), 2, 4, lds_chunk=64)   # 300 triangles -> 5 chunks
-    assert g.Info()["lds_chunk"] == 64 and g.Info()["lds_bytes"] == 64 * 48
+    assert g.Info()["lds_chunk"] == 64 and g.Info()["lds_bytes"] == 64 * 36
     assert_frame_equal(g, o)
 
 

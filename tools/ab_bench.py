@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Kernel A/B helper: time the trace kernel of several builds of librt_mi355x.so (and
+launch options) on the same device, each in its own subprocess, several rounds
+interleaved.  Usage: tools/ab_bench.py --config C3 --rounds 3 name=lib.so[,k=4][,chunk=1024] ..."""
+import argparse
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import json, os, sys
+sys.path.insert(0, %(root)r)
+import raytracertest_amd as R
+from raytracertest_amd import scenes
+cfg = dict(scenes.CONFIGS[%(config)r]); tris, sph = scenes.scene_for(%(config)r)
+g = R.RayTracer((cfg["width"], cfg["height"]), (0, 0, 0), cfg["angles"], cfg["fov"], cfg["focal"], cfg["aperture"],
+                seed=cfg["seed"], samples_in_flight=%(k)d, lds_chunk=%(chunk)d, no_filter=%(nofilter)r)
+if tris.shape[0]: g.UploadScene(tris)
+if sph.shape[0]: g.UploadSpheres(sph)
+for _ in range(%(warmup)d): g.TraceEnqueue(1, cfg["samples"])
+g.Sync(); g.KernelTime()
+for _ in range(%(steps)d): g.TraceEnqueue(1, cfg["samples"])
+g.Sync(); ms, n = g.KernelTime()
+print(json.dumps({"us": ms / n * 1e3, "info": g.Info()}))
+'''
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="C3")
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("variants", nargs="+")
+    a = ap.parse_args()
+    variants = []
+    for v in a.variants:
+        name, rest = v.split("=", 1)
+        parts = rest.split(",")
+        opts = {"lib": parts[0], "k": 0, "chunk": 0, "nofilter": False}
+        for p in parts[1:]:
+            key, val = p.split("=")
+            opts[key] = (val == "1") if key == "nofilter" else int(val)
+        variants.append((name, opts))
+    res = {n: [] for n, _ in variants}
+    for _ in range(a.rounds):
+        for name, o in variants:
+            env = dict(os.environ)
+            lib = o["lib"]
+            env["RT_MI355X_LIB"] = lib if os.path.isabs(lib) else os.path.join(ROOT, "raytracertest_amd", "lib", lib)
+            code = CHILD % dict(root=ROOT, config=a.config, k=o["k"], chunk=o["chunk"], nofilter=o["nofilter"],
+                                warmup=a.warmup, steps=a.steps)
+            out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+            if out.returncode != 0:
+                print(name, "FAILED", out.stderr[-400:])
+                continue
+            res[name].append(json.loads(out.stdout.strip().splitlines()[-1])["us"])
+    for name, _ in variants:
+        v = sorted(res[name])
+        if v:
+            print("%-22s min %10.1f us  median %10.1f us  (%s)" % (name, v[0], v[len(v) // 2], ", ".join("%.1f" % x for x in res[name])))
+
+
+if __name__ == "__main__":
+    main()
