@@ -39,6 +39,8 @@ extern "C" {
 #define RT_MATH_STRICT     1u  /* every source-level operation rounds separately */
 
 #define RT_FLAG_NO_FILTER  1u  /* disable the conservative wave-uniform rejections (debug / parity tests) */
+#define RT_FLAG_NO_BINNING 2u  /* disable the per-tile triangle classification: every ray scans the whole
+                                  list from block-staged LDS chunks (debug / parity tests / A-B) */
 
 #define RT_BUF_RENDER      0   /* rows*W*4 float  RGBA accumulators   (mRenderBuffer)      */
 #define RT_BUF_COUNTS      1   /* rows*W   uint32 sample counts       (mSampleCountBuffer) */
@@ -128,8 +130,11 @@ int  rt_tracer_kernel_time(rt_tracer* t, double* total_ms, uint64_t* launches, i
  *   out[0..3] ray-triangle tests by the reference's exit point: culled at det
  *             (Kernels.cuh:42), rejected at u (:51), rejected at v (:58), full hit (:63);
  *   out[4..7] (wave, triangle) pairs skipped by the __ballot early-outs after stage A
- *             (culling), B (u), C (v), and pairs that reached the exact stage D. */
-int  rt_tracer_trace_stats(rt_tracer* t, uint32_t samples, uint64_t out[8]);
+ *             (culling), B (u), C (v), and pairs that reached the exact stage D;
+ *   out[8]    candidate triangles kept by the per-tile classification, summed over waves and
+ *             rounds; out[9] classification rounds (one per wave when its list fits in LDS).
+ *   out[10..15] reserved. */
+int  rt_tracer_trace_stats(rt_tracer* t, uint32_t samples, uint64_t out[16]);
 /* Copy one of the tracer's device buffers to host memory / to another device pointer. */
 int  rt_tracer_read_buffer(rt_tracer* t, int which, void* dst, size_t bytes);
 int  rt_tracer_copy_buffer_to_device(rt_tracer* t, int which, void* dst_device, size_t bytes);

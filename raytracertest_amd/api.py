@@ -18,6 +18,7 @@ _LIB_PATH = os.environ.get("RT_MI355X_LIB") or os.path.join(_HERE, "lib", "librt
 
 MATH_FMA, MATH_STRICT = 0, 1
 FLAG_NO_FILTER = 1
+FLAG_NO_BINNING = 2
 BUF_RENDER, BUF_COUNTS, BUF_IMAGE, BUF_RNG = 0, 1, 2, 3
 
 # every symbol include/rt_mi355x.h declares (checked by tests/test_abi.py)
@@ -136,7 +137,8 @@ class RayTracer:
 
     def __init__(self, imageSize, cameraPosition=(0.0, 0.0, 0.0), cameraAngles=(0.0, 0.0), fov=70.0,
                  focalLength=10.0, aperture=4.0, *, seed=None, device=0, math_mode=MATH_FMA,
-                 full_height=0, row_begin=0, no_filter=False, samples_in_flight=0, lds_chunk=0):
+                 full_height=0, row_begin=0, no_filter=False, no_binning=False, samples_in_flight=0,
+                 lds_chunk=0):
         self._lib = load_library()
         self._h = C.c_void_p()
         self._cbs = {}
@@ -148,7 +150,7 @@ class RayTracer:
         opt.use_time_seed = 1 if seed is None else 0          # Random.cu:45 when no seed is given
         opt.seed = 0 if seed is None else int(seed)
         opt.math_mode = math_mode
-        opt.flags = FLAG_NO_FILTER if no_filter else 0
+        opt.flags = (FLAG_NO_FILTER if no_filter else 0) | (FLAG_NO_BINNING if no_binning else 0)
         opt.samples_in_flight, opt.lds_chunk = samples_in_flight, lds_chunk
         rc = self._lib.rt_tracer_create_ex(_u32p(size), _f32p(np.array(cameraPosition, np.float32)),
                                            _f32p(np.array(cameraAngles, np.float32)), fov, focalLength,
@@ -211,11 +213,12 @@ class RayTracer:
 
     def TraceStats(self, samples):
         """One instrumented launch; see rt_tracer_trace_stats in include/rt_mi355x.h."""
-        out = (C.c_uint64 * 8)()
+        out = (C.c_uint64 * 16)()
         self._check(self._lib.rt_tracer_trace_stats(self._h, samples, out))
         v = [int(x) for x in out]
         return {"exit_det": v[0], "exit_u": v[1], "exit_v": v[2], "exit_hit": v[3],
-                "skip_a": v[4], "skip_b": v[5], "skip_c": v[6], "reach_d": v[7]}
+                "skip_a": v[4], "skip_b": v[5], "skip_c": v[6], "reach_d": v[7],
+                "bin_candidates": v[8], "bin_rounds": v[9]}
 
     def KernelTime(self, reset=True):
         ms, n = C.c_double(), C.c_uint64()

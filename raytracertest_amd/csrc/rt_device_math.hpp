@@ -73,9 +73,12 @@ __host__ __device__ __forceinline__ void sincos_spec(float x, float& s, float& c
   const float pc = __builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z,
                                   4.166664568298827e-2f);
   const float cs = __builtin_fmaf(z * z, pc, __builtin_fmaf(-0.5f, z, 1.0f));
+  // quadrant q = k mod 4: (sin, cos) = (sn, cs), (cs, -sn), (-sn, -cs), (-cs, sn); branch-free
   const int q = static_cast<int>(k) & 3;
-  s = (q == 0) ? sn : (q == 1) ? cs : (q == 2) ? -sn : -cs;
-  c = (q == 0) ? cs : (q == 1) ? -sn : (q == 2) ? -cs : sn;
+  const float ss = (q & 1) ? cs : sn;
+  const float cc = (q & 1) ? sn : cs;
+  s = (q & 2) ? -ss : ss;
+  c = ((q + 1) & 2) ? -cc : cc;
 }
 
 // ---- XORWOW (cuRAND's curandState_t generator restated; Random.cuh:15-16,23) ----------
@@ -91,7 +94,8 @@ __device__ __forceinline__ uint32_t rng_next(Rng& s) {
 
 // curand_uniform: x * 2^-32 + 2^-33, (0, 1]
 __device__ __forceinline__ float rng_uniform(Rng& s) {
-  return static_cast<float>(rng_next(s)) * 2.3283064e-10f + (2.3283064e-10f / 2.0f);
+  // x * 2^-32 is exact, so the single fma rounds exactly like the reference's mul + add
+  return __builtin_fmaf(static_cast<float>(rng_next(s)), 2.3283064e-10f, 2.3283064e-10f / 2.0f);
 }
 
 // random::UnifromOnDisk, Random.cuh:13-19 (the mistyped pi literal is the reference's)

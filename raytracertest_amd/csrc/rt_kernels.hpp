@@ -25,15 +25,17 @@ struct TraceParams {
   const float4* spheres;    // centre xyz, radius (build-defined extension)
   uint32_t  n_spheres;
   uint32_t  chunk;          // triangles staged into LDS at a time
-  unsigned long long* stats; // null in the product path; 8 counters for the instrumented launch
+  unsigned long long* stats; // null in the product path; 16 counters for the instrumented launch
 };
 
 hipError_t launch_rng_init(uint32_t* rng, uint32_t npix, uint32_t p0, const uint32_t seeded[6],
                            const uint32_t* jump, hipStream_t st);
 hipError_t launch_prep_triangles(bool fma, const float4* verts, uint32_t n, float4* tri_a, float* tri_b,
                                  float4* color, hipStream_t st);
-uint32_t trace_lds_bytes(const TraceParams& p);
-hipError_t launch_trace(const TraceParams& p, bool fma, bool filter, int K, hipStream_t st);
+uint32_t trace_lds_bytes(const TraceParams& p, bool bin);
+// bin: per-tile triangle classification + per-wave LDS candidate lists (rt_trace.hpp);
+// !bin: every ray scans the whole list, staged into LDS in chunks of p.chunk.
+hipError_t launch_trace(const TraceParams& p, bool fma, bool filter, bool bin, int K, hipStream_t st);
 hipError_t launch_convert(const float4* render, const uint32_t* counts, uint32_t* image, uint32_t npix,
                           hipStream_t st);
 

@@ -1,0 +1,564 @@
+// rt_trace.hpp -- the trace kernel (rt::TraceKernel + Radiance + HitTriangle +
+// ThinLensCamera::GetRay; RayTracer/Kernels.cuh:29-147, ThinLensCamera.cuh:30-52,111-130).
+// Included by rt_kernels.hip only.
+//
+// Execution shape (MI355X: 256 CUs x 4 SIMD, wave64, 160 KiB LDS/CU):
+//   * one lane = one pixel; a wave covers an 8x8 pixel tile, a 256-thread block 32x8 pixels,
+//     so every 128-byte line of the per-pixel buffers is read and written whole by one block;
+//   * every lane keeps K samples of its pixel in registers and tests them against one
+//     triangle at a time; the 36-byte triangle record is read from LDS with wave-uniform
+//     (broadcast) ds_read_b128 x2 (+ ds_read_b32), amortised over 64*K rays;
+//   * triangles are always scanned in ascending index order (first-scanned wins ties,
+//     Kernels.cuh:84);
+//   * __ballot-driven wave-uniform early-outs after the culling test, the u test and the v
+//     test (FILTER); the IEEE division only runs for triangles some lane may really hit;
+//   * BIN: before tracing, each wave classifies the whole triangle list against the ray
+//     family of its tile (lane = triangle, interval bounds) and compacts the survivors with
+//     __ballot + mbcnt into a per-wave LDS candidate list, so the exact tests run only on
+//     triangles some ray of the tile could hit.  Without BIN the block stages the list into
+//     LDS in chunks and every ray scans all of it.
+#pragma once
+#include <float.h>
+
+#include "rt_device_math.hpp"
+#include "rt_kernels.hpp"
+
+namespace rtk {
+
+using rtd::Math;
+using rtd::Rng;
+using rtd::V3;
+
+#define RT_EPS 0.0000000001f
+#ifndef RT_TRACE_MIN_WAVES
+#define RT_TRACE_MIN_WAVES 4     // __launch_bounds__ 2nd argument: waves per SIMD the allocator must allow
+                                 // (<= 128 VGPRs; measured C3 213 -> 193 us, C4 27.2 -> 24.3 ms vs the 136-VGPR build)
+#endif
+#define RT_BIN_LIST 256u         // candidate records per wave in LDS (40 bytes each)
+
+// ------------------------------------------------------------------------------------
+// Exact HitTriangle in the reference's operation order (Kernels.cuh:29-65) on a
+// precomputed (v0, e1, e2).  Used by the unfiltered trace path and the dbg harness.
+// `stage` reports the exit point: 0 culled at det, 1 rejected at u, 2 rejected at v, 3 hit.
+// ------------------------------------------------------------------------------------
+template <bool FMA>
+__device__ __forceinline__ bool hit_triangle_exact(V3 o, V3 d, V3 v0, V3 e1, V3 e2, float eps,
+                                                   float& t, float& u, float& v, int& stage) {
+  using M = Math<FMA>;
+  stage = 0;
+  const V3 pv = M::cross(d, e2);                       // :39
+  const float det = M::dot(e1, pv);                    // :40
+  if (det < eps) return false;                         // :42
+  stage = 1;
+  const float inv = 1.0f / det;                        // :47
+  const V3 tv = rtd::sub(o, v0);                       // :49
+  u = M::dot(tv, pv) * inv;                            // :50
+  if (u < 0.0f || u > 1.0f) return false;              // :51
+  stage = 2;
+  const V3 qv = M::cross(tv, e1);                      // :56
+  v = M::dot(d, qv) * inv;                             // :57
+  if (v < 0.0f || u + v > 1.0f) return false;          // :58
+  stage = 3;
+  t = M::dot(e2, qv) * inv;                            // :63
+  return true;
+}
+
+// Build-defined ray-sphere (Documentation/ray.sphere.png; absent from the reference code)
+template <bool FMA>
+__device__ __forceinline__ bool hit_sphere(V3 o, V3 d, float4 sph, float& t) {
+  using M = Math<FMA>;
+  const V3 vv = rtd::sub(o, {sph.x, sph.y, sph.z});
+  const float a = M::dot(d, d);
+  const float b = 2.0f * M::dot(vv, d);
+  const float dvv = M::dot(vv, vv);
+  float cc, disc;
+  if constexpr (FMA) {
+    cc = __builtin_fmaf(-sph.w, sph.w, dvv);
+    disc = __builtin_fmaf(b, b, -((4.0f * a) * cc));
+  } else {
+    cc = dvv - sph.w * sph.w;
+    disc = b * b - (4.0f * a) * cc;
+  }
+  if (disc < 0.0f) return false;
+  t = (-b - __builtin_sqrtf(disc)) / (2.0f * a);
+  return true;
+}
+
+// ThinLensCamera::PinHoleRay, ThinLensCamera.cuh:111-130 (tan(fov/2) and aspect are
+// launch constants computed once on the host with the same operations)
+template <bool FMA>
+__device__ __forceinline__ void pinhole(const TraceParams& p, uint32_t px, uint32_t py, V3& o, V3& d) {
+  using M = Math<FMA>;
+  const float nx = (static_cast<float>(px) + 0.5f) / static_cast<float>(p.W);     // :116
+  const float ny = (static_cast<float>(py) + 0.5f) / static_cast<float>(p.H);     // :117
+  const float cx = ((2.0f * nx - 1.0f) * p.half_height) * p.aspect;               // :118
+  const float cy = (1.0f - 2.0f * ny) * p.half_height;                            // :119
+  o = M::mat_mul_point(p.cam, 0.0f, 0.0f, 0.0f, 1.0f);                            // :124
+  const V3 pw = M::mat_mul_point(p.cam, cx, cy, -1.0f, 1.0f);                     // :125
+  d = M::normalize(rtd::sub(pw, o));                                              // :127-128
+}
+
+// focal point of a pixel, ThinLensCamera.cuh:44: Position() + mFocalLength * primary.direction()
+template <bool FMA>
+__device__ __forceinline__ V3 focal_point(const TraceParams& p, V3 pd) {
+  using M = Math<FMA>;
+  return {M::madd1(p.focal, pd.x, p.cam[9]), M::madd1(p.focal, pd.y, p.cam[10]),
+          M::madd1(p.focal, pd.z, p.cam[11])};
+}
+
+// ThinLensCamera::GetRay, ThinLensCamera.cuh:30-52; `focal` is the pixel's focal point
+// (sample-invariant, hoisted)
+template <bool FMA>
+__device__ __forceinline__ void get_ray(const TraceParams& p, V3 focal, Rng& rng, V3& o, V3& d) {
+  using M = Math<FMA>;
+  float dx, dy;
+  rtd::uniform_on_disk(rng, dx, dy);                                              // :41
+  const V3 pos = {p.cam[9], p.cam[10], p.cam[11]};                                // Position(), :54-57
+  const V3 off = {dx * p.aperture, dy * p.aperture, 0.0f};
+  o = rtd::add(pos, off);                                                         // :47
+  d = M::normalize(rtd::sub(focal, o));                                           // :50
+}
+
+// ------------------------------------------------------------------------------------
+// One triangle against the K rays of every lane.
+//
+// FILTER: three wave-uniform early-outs, decided with __ballot on CONSERVATIVE per-ray
+// rejections -- a ray is only ever dropped when the reference's own test is certain to
+// miss, and the triangle is skipped only when every ray of the wave is dropped; whenever
+// any ray survives, stage D evaluates the reference's exact test (division included) for
+// all lanes from the values already computed.  With u = fl(U*inv), v = fl(V*inv),
+// inv = fl(1/det), det >= 1e-10 (not culled):
+//   U > fl(det*1.0001)            => U/det > 1.00009            => u > 1      (miss, :51)
+//   U < fl(det*-1e-6)             => U/det < -0.99e-6 (normal)  => u < 0      (miss, :51)
+//   V < fl(det*-1e-6)             =>                               v < 0      (miss, :58)
+//   U+V > fl(det*1.0001), with U,V >= -1e-6 det (not dropped above)
+//                                 => u+v > 1.0001 - 4e-6 - roundoff > 1       (miss, :58)
+// NaN/inf operands make every comparison false: the ray is kept and stage D decides.
+// tests/test_gpu_parity.py::test_filter_off_equals_filter_on checks FILTER against the
+// plain reference-order path bit for bit.
+// ------------------------------------------------------------------------------------
+template <bool FMA, int K, bool FILTER, bool STATS, class GetB>
+__device__ __forceinline__ void test_triangle(const float4 A0, const float4 A1, GetB get_v0z, int tri_index,
+                                              const V3 (&o)[K], const V3 (&d)[K], float (&best_t)[K],
+                                              int (&best_i)[K], bool counted_lane, uint32_t valid_k,
+                                              unsigned long long (&st_exit)[4],
+                                              unsigned long long (&st_skip)[4]) {
+  using M = Math<FMA>;
+  const V3 e2 = {A0.x, A0.y, A0.z}, e1 = {A0.w, A1.x, A1.y};
+
+  if constexpr (!FILTER) {
+    const V3 v0 = {A1.z, A1.w, get_v0z()};
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      float t = 0.0f, u = 0.0f, v = 0.0f;
+      int stage;
+      const bool h = hit_triangle_exact<FMA>(o[k], d[k], v0, e1, e2, RT_EPS, t, u, v, stage);
+      if (h && best_t[k] < t) {                                    // :84
+        best_t[k] = t;
+        best_i[k] = tri_index;
+      }
+      if constexpr (STATS) {
+        const bool counted = counted_lane && (static_cast<uint32_t>(k) < valid_k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          st_exit[e] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(counted && stage == e));
+      }
+    }
+  } else {
+    // stage A: pv = cross(dir, e2), det = dot(e1, pv), culling (:39-45)
+    V3 pv[K];
+    float det[K];
+    unsigned long long mk[K];
+    unsigned long long live = 0ull;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      pv[k] = M::cross(d[k], e2);
+      det[k] = M::dot(e1, pv[k]);
+      mk[k] = __builtin_amdgcn_ballot_w64(!(det[k] < RT_EPS));
+      live |= mk[k];
+    }
+    if (live == 0ull) { if constexpr (STATS) st_skip[0]++; return; }   // whole wave culled
+
+    // stage B: U = dot(origin - v0, pv) (:49-50), conservative u rejection
+    const V3 v0 = {A1.z, A1.w, get_v0z()};
+    V3 tv[K];
+    float U[K], thi[K], tlo[K];
+    live = 0ull;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      tv[k] = rtd::sub(o[k], v0);
+      U[k] = M::dot(tv[k], pv[k]);
+      thi[k] = det[k] * 1.0001f;
+      tlo[k] = det[k] * -1e-6f;
+      mk[k] &= __builtin_amdgcn_ballot_w64(!(U[k] > thi[k])) & __builtin_amdgcn_ballot_w64(!(U[k] < tlo[k]));
+      live |= mk[k];
+    }
+    if (live == 0ull) { if constexpr (STATS) st_skip[1]++; return; }
+
+    // stage C: V = dot(dir, cross(tv, e1)) (:56-57), conservative v rejection
+    V3 qv[K];
+    float V[K];
+    live = 0ull;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      qv[k] = M::cross(tv[k], e1);
+      V[k] = M::dot(d[k], qv[k]);
+      mk[k] &= __builtin_amdgcn_ballot_w64(!(V[k] < tlo[k])) &
+               __builtin_amdgcn_ballot_w64(!((U[k] + V[k]) > thi[k]));
+      live |= mk[k];
+    }
+    if (live == 0ull) { if constexpr (STATS) st_skip[2]++; return; }
+    if constexpr (STATS) st_skip[3]++;
+
+    // stage D: the reference's exact tests (:42-63, :84) wherever a ray may hit
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (mk[k] != 0ull) {
+        const float inv = 1.0f / det[k];                           // :47
+        const float u = U[k] * inv;                                // :50
+        const float v = V[k] * inv;                                // :57
+        const float t = M::dot(e2, qv[k]) * inv;                   // :63
+        const bool miss = (det[k] < RT_EPS) | (u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f);
+        const bool upd = (!miss) & (best_t[k] < t);                // :84
+        best_t[k] = upd ? t : best_t[k];
+        best_i[k] = upd ? tri_index : best_i[k];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// BIN: conservative classification of one triangle against the whole ray family of a tile.
+//
+// Ray family of a wave: every lens origin o in the box oc +- orad and every direction d in
+// the box dc +- drad (bounds over all 64 pixels of the tile and the whole lens disk, widened
+// for rounding; built by tile_family()).  For any such ray let det, U, V be the values the
+// REFERENCE arithmetic computes (either math mode).  With midpoint-radius interval
+// arithmetic (P = abscross(|d|max, |e2|), T = |tv|max, Q = abscross(T, |e1|)):
+//   |det - detc| <= dot(|e1|, pvr) + c*dot(|e1|, P)                    =: det_rad
+//   |U   - Uc  | <= dot(|tvc|, pvr) + dot(tvr, |pvc| + pvr) + c*dot(T, P)  =: U_rad
+//   |V   - Vc  | <= dot(|dc|, qvr) + dot(drad, |qvc| + qvr) + c*dot(|d|max, Q) =: V_rad
+// where pvr = abscross(drad, |e2|), qvr = abscross(tvr, |e1|) are the interval radii and
+// c = 4e-6 (~67 ulp) dominates every rounding error of the reference's evaluation AND of
+// this one (each is <= ~10 ulp of the same magnitude sums).  The triangle can be dropped
+// for the whole tile when one of the following holds for the interval ends, because then
+// the per-ray rules proven above test_triangle() make every ray of the family a certain miss:
+//   det_hi < eps                                   every ray culled (:42)
+//   U_hi < -1e-6 * det_hi     (det_hi > 0)         every unculled ray has u < 0
+//   U_lo > 1.0002 * det_hi                         every unculled ray has u > 1
+//   V_hi < -1e-6 * det_hi                          every remaining ray has v < 0
+//   U_lo + V_lo > 1.0002 * det_hi                  every remaining ray has u + v > 1
+// Any NaN makes the comparisons false -> the triangle is kept and the exact tests decide.
+// tests/test_gpu_parity.py::test_binning_* compare BIN against the full scan bit for bit.
+// ------------------------------------------------------------------------------------
+struct TileFamily {
+  float oc[3], orad[3];   // lens origin box (wave-uniform)
+  float dc[3], drad[3];   // direction box  (wave-uniform)
+  bool usable;            // false: bounds not finite -> keep every triangle
+};
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// Bounds of (origin, direction) over every sample of every in-image pixel of the wave.
+// o = pos + (dx*aperture, dy*aperture, 0) with |dx|,|dy| <= 1.0000003 (sr <= 1, build-owned
+// sincos within 2 ulp of [-1,1]); d = normalize(focal_pixel - o) up to ~5 ulp.
+__device__ __forceinline__ TileFamily tile_family(const TraceParams& p, V3 focal, bool inside) {
+  TileFamily f;
+  const float A = __builtin_fabsf(p.aperture) * 1.000002f;
+  f.oc[0] = p.cam[9]; f.oc[1] = p.cam[10]; f.oc[2] = p.cam[11];
+  f.orad[0] = A + 1e-6f * __builtin_fabsf(f.oc[0]);
+  f.orad[1] = A + 1e-6f * __builtin_fabsf(f.oc[1]);
+  f.orad[2] = 1e-6f * __builtin_fabsf(f.oc[2]);
+  const float fc[3] = {focal.x, focal.y, focal.z};
+  float lo[3], hi[3], lmin2 = 0.0f, lmax2 = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float wc = fc[i] - f.oc[i];
+    const float wr = f.orad[i] + 2e-7f * (__builtin_fabsf(fc[i]) + __builtin_fabsf(f.oc[i]));
+    lo[i] = wc - wr;
+    hi[i] = wc + wr;
+    const float amin = fmaxf(__builtin_fabsf(wc) - wr, 0.0f), amax = __builtin_fabsf(wc) + wr;
+    lmin2 = __builtin_fmaf(amin, amin, lmin2);
+    lmax2 = __builtin_fmaf(amax, amax, lmax2);
+  }
+  const float rlo = (1.0f / __builtin_sqrtf(lmax2)) * 0.999998f;    // smallest 1/|w|
+  const float rhi = (1.0f / __builtin_sqrtf(lmin2)) * 1.000002f;    // largest  1/|w| (inf when the box touches 0)
+  bool finite = true;
+  float dlo[3], dhi[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float a = (lo[i] >= 0.0f) ? lo[i] * rlo : lo[i] * rhi;
+    float b = (hi[i] >= 0.0f) ? hi[i] * rhi : hi[i] * rlo;
+    finite = finite && (__builtin_fabsf(a) <= 2.0f) && (__builtin_fabsf(b) <= 2.0f);   // false for NaN/inf
+    if (!inside) { a = FLT_MAX; b = -FLT_MAX; }                     // out-of-image lanes do not constrain
+    dlo[i] = wave_min(a);
+    dhi[i] = wave_max(b);
+  }
+  const bool bad = __builtin_amdgcn_ballot_w64(inside && !finite) != 0ull;
+  const bool any_inside = __builtin_amdgcn_ballot_w64(inside) != 0ull;
+  f.usable = !bad && any_inside && (A <= FLT_MAX);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    f.dc[i] = 0.5f * (dlo[i] + dhi[i]);
+    f.drad[i] = 0.5f * (dhi[i] - dlo[i]) * 1.00001f + 2e-6f;
+  }
+  return f;
+}
+
+// true = every ray of the family certainly misses this triangle (see the block comment)
+__device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0, V3 e1, V3 e2) {
+  const float c = 4e-6f;
+  const float E1[3] = {__builtin_fabsf(e1.x), __builtin_fabsf(e1.y), __builtin_fabsf(e1.z)};
+  const float E2[3] = {__builtin_fabsf(e2.x), __builtin_fabsf(e2.y), __builtin_fabsf(e2.z)};
+  const float e1v[3] = {e1.x, e1.y, e1.z}, e2v[3] = {e2.x, e2.y, e2.z}, v0v[3] = {v0.x, v0.y, v0.z};
+  float D[3], tvc[3], tvr[3], T[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    D[i] = __builtin_fabsf(f.dc[i]) + f.drad[i];
+    tvc[i] = f.oc[i] - v0v[i];
+    tvr[i] = f.orad[i] + 2e-7f * (__builtin_fabsf(f.oc[i]) + __builtin_fabsf(v0v[i]));
+    T[i] = __builtin_fabsf(tvc[i]) + tvr[i];
+  }
+  // cross(a, b)_i = a_j*b_k - b_j*a_k with (i,j,k) cyclic
+  float pvc[3], pvr[3], P[3], qvc[3], qvr[3], Q[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int j = (i + 1) % 3, k = (i + 2) % 3;
+    pvc[i] = f.dc[j] * e2v[k] - e2v[j] * f.dc[k];                   // cross(d, e2)
+    pvr[i] = f.drad[j] * E2[k] + E2[j] * f.drad[k];
+    P[i] = D[j] * E2[k] + E2[j] * D[k];
+    qvc[i] = tvc[j] * e1v[k] - e1v[j] * tvc[k];                     // cross(tv, e1)
+    qvr[i] = tvr[j] * E1[k] + E1[j] * tvr[k];
+    Q[i] = T[j] * E1[k] + E1[j] * T[k];
+  }
+  float detc = 0.0f, det_rad = 0.0f, Uc = 0.0f, U_rad = 0.0f, Vc = 0.0f, V_rad = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    detc += e1v[i] * pvc[i];
+    det_rad += E1[i] * pvr[i] + c * (E1[i] * P[i]);
+    Uc += tvc[i] * pvc[i];
+    U_rad += __builtin_fabsf(tvc[i]) * pvr[i] + tvr[i] * (__builtin_fabsf(pvc[i]) + pvr[i]) + c * (T[i] * P[i]);
+    Vc += f.dc[i] * qvc[i];
+    V_rad += __builtin_fabsf(f.dc[i]) * qvr[i] + f.drad[i] * (__builtin_fabsf(qvc[i]) + qvr[i]) + c * (D[i] * Q[i]);
+  }
+  det_rad = det_rad * 1.00001f;
+  U_rad = U_rad * 1.00001f;
+  V_rad = V_rad * 1.00001f;
+  const float det_hi = detc + det_rad;
+  const float U_lo = Uc - U_rad, U_hi = Uc + U_rad, V_lo = Vc - V_rad, V_hi = Vc + V_rad;
+  const float neg = det_hi * -1e-6f, big = det_hi * 1.0002f;
+  const bool all_culled = det_hi < RT_EPS;
+  const bool pos = det_hi > 0.0f;
+  const bool out = pos && ((U_hi < neg) || (U_lo > big) || (V_hi < neg) || ((U_lo + V_lo) > big));
+  return all_culled || out;
+}
+
+// ------------------------------------------------------------------------------------
+// The trace kernel.  grid = (ceil(W/32), ceil(rows/8)), block = 256 threads.
+// Dynamic LDS: BIN ? 4 waves * RT_BIN_LIST * 40 bytes : min(n_tris, chunk) * 36 bytes.
+// ------------------------------------------------------------------------------------
+template <bool FMA, int K, bool FILTER, bool STATS, bool BIN>
+__global__ __launch_bounds__(256, RT_TRACE_MIN_WAVES) void trace_kernel(const TraceParams p) {
+  using M = Math<FMA>;
+  extern __shared__ float4 s_mem[];
+
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t px = blockIdx.x * 32u + wave * 8u + (lane & 7u);
+  const uint32_t ly = blockIdx.y * 8u + (lane >> 3);
+  const bool inside = px < p.W && ly < p.rows;
+  const uint32_t cxp = inside ? px : 0u, cyp = inside ? ly : 0u;   // out-of-image lanes shadow pixel 0
+  const size_t pix = static_cast<size_t>(cxp) + static_cast<size_t>(cyp) * p.W;   // Kernels.cuh:128
+
+  Rng rng;                                                         // :131
+  rng.d = p.rng[0 * static_cast<size_t>(p.npix) + pix];
+  rng.v0 = p.rng[1 * static_cast<size_t>(p.npix) + pix];
+  rng.v1 = p.rng[2 * static_cast<size_t>(p.npix) + pix];
+  rng.v2 = p.rng[3 * static_cast<size_t>(p.npix) + pix];
+  rng.v3 = p.rng[4 * static_cast<size_t>(p.npix) + pix];
+  rng.v4 = p.rng[5 * static_cast<size_t>(p.npix) + pix];
+
+  V3 po, pd;
+  pinhole<FMA>(p, cxp, p.row0 + cyp, po, pd);
+  const V3 focal = focal_point<FMA>(p, pd);
+
+  const uint32_t n = p.n_tris;
+  float ax = 0.0f, ay = 0.0f, az = 0.0f;                           // accu, :133
+  unsigned long long st_exit[4] = {0, 0, 0, 0};                    // STATS: lane-tests by exit point
+  unsigned long long st_skip[4] = {0, 0, 0, 0};                    // STATS: wave-triangles skipped after A/B/C, reaching D
+  unsigned long long st_bin[2] = {0, 0};                           // STATS: candidates kept, classification rounds
+
+  // ---- full-scan staging (BIN == false) --------------------------------------------------
+  const uint32_t cap = n < p.chunk ? n : p.chunk;                  // triangles resident in LDS
+  float4* const sA = s_mem;                                        // 2 float4 per triangle
+  float* const sB = reinterpret_cast<float*>(s_mem + 2u * cap);    // 1 float per triangle
+  const bool single_chunk = n <= p.chunk;
+  if constexpr (!BIN) {
+    if (single_chunk) {
+      for (uint32_t i = threadIdx.x; i < 2u * n; i += 256u) sA[i] = p.tri_a[i];
+      for (uint32_t i = threadIdx.x; i < n; i += 256u) sB[i] = p.tri_b[i];
+      __syncthreads();
+    }
+  }
+
+  // ---- per-wave candidate list (BIN == true) ---------------------------------------------
+  float4* const cA = s_mem + static_cast<size_t>(wave) * (2u * RT_BIN_LIST);               // 2 float4 per candidate
+  float* const cB = reinterpret_cast<float*>(s_mem + 4u * 2u * RT_BIN_LIST) + wave * RT_BIN_LIST;
+  int* const cI = reinterpret_cast<int*>(s_mem + 4u * 2u * RT_BIN_LIST) + 4u * RT_BIN_LIST + wave * RT_BIN_LIST;
+  TileFamily fam;
+  bool list_complete = false;       // the list in LDS covers the whole scene (classification done once)
+  uint32_t list_count = 0;
+  if constexpr (BIN) fam = tile_family(p, focal, inside);
+
+  // classify triangles [from, n) until the list is full; returns the first unclassified index
+  auto classify = [&](uint32_t from) -> uint32_t {
+    uint32_t count = 0, base = from;
+    while (base < n && count + 64u <= RT_BIN_LIST) {
+      const uint32_t tri = base + lane;
+      const bool valid = tri < n;
+      const uint32_t ti = valid ? tri : (n - 1u);
+      const float4 A0 = p.tri_a[2u * ti], A1 = p.tri_a[2u * ti + 1u];
+      const float bz = p.tri_b[ti];
+      bool keep = valid;
+      if (fam.usable)
+        keep = valid && !tile_misses_triangle(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z});
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+      const uint32_t pos = count + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
+                                                             __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+      if (keep) {                                                  // ascending order is preserved
+        cA[2u * pos] = A0;
+        cA[2u * pos + 1u] = A1;
+        cB[pos] = bz;
+        cI[pos] = static_cast<int>(tri);
+      }
+      count += static_cast<uint32_t>(__builtin_popcountll(m));
+      base += 64u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        // this wave's ds_writes before its ds_reads
+    __builtin_amdgcn_wave_barrier();
+    list_count = count;
+    if constexpr (STATS) { st_bin[0] += count; st_bin[1] += 1; }
+    return base < n ? base : n;
+  };
+
+  for (uint32_t s0 = 0; s0 < p.samples; s0 += K) {                 // :134, K samples per pass
+    V3 o[K], d[K];
+    float best_t[K];
+    int best_i[K];
+    const uint32_t valid_k = (p.samples - s0 < static_cast<uint32_t>(K)) ? p.samples - s0 : static_cast<uint32_t>(K);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (static_cast<uint32_t>(k) < valid_k) get_ray<FMA>(p, focal, rng, o[k], d[k]);   // :136
+      else { o[k] = po; d[k] = pd; }                               // padding ray, result discarded
+      best_t[k] = -FLT_MAX;                                        // :73
+      best_i[k] = -1;
+    }
+
+    if constexpr (BIN) {
+      uint32_t base = 0;
+      do {
+        uint32_t next = n;
+        if (!list_complete) {
+          next = classify(base);
+          if (base == 0u && next >= n) list_complete = true;
+        }
+        for (uint32_t j = 0; j < list_count; ++j) {                // ascending triangle order
+          const float4 A0 = cA[2u * j], A1 = cA[2u * j + 1u];
+          test_triangle<FMA, K, FILTER, STATS>(A0, A1, [&] { return cB[j]; }, cI[j], o, d, best_t, best_i,
+                                               inside, valid_k, st_exit, st_skip);
+        }
+        base = next;
+        if (!list_complete) __builtin_amdgcn_wave_barrier();       // list is rewritten by the next round
+      } while (!list_complete && base < n);
+    } else {
+      for (uint32_t c0 = 0; c0 < n; c0 += p.chunk) {
+        const uint32_t cn = (n - c0 < p.chunk) ? n - c0 : p.chunk;
+        if (!single_chunk) {
+          __syncthreads();                                         // everyone done with the previous chunk
+          for (uint32_t i = threadIdx.x; i < 2u * cn; i += 256u) sA[i] = p.tri_a[2u * c0 + i];
+          for (uint32_t i = threadIdx.x; i < cn; i += 256u) sB[i] = p.tri_b[c0 + i];
+          __syncthreads();
+        }
+        for (uint32_t j = 0; j < cn; ++j) {                        // :75, ascending order
+          const float4 A0 = sA[2u * j], A1 = sA[2u * j + 1u];
+          test_triangle<FMA, K, FILTER, STATS>(A0, A1, [&] { return sB[j]; }, static_cast<int>(c0 + j), o, d,
+                                               best_t, best_i, inside, valid_k, st_exit, st_skip);
+        }
+      }
+    }
+
+    // spheres continue the same farthest-hit scan, then shade in sample order (:95-104, :137)
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (static_cast<uint32_t>(k) < valid_k) {
+        float dist = best_t[k];
+        int win = best_i[k];
+        for (uint32_t si = 0; si < p.n_spheres; ++si) {
+          float t = 0.0f;
+          if (hit_sphere<FMA>(o[k], d[k], p.spheres[si], t) && dist < t) {
+            dist = t;
+            win = static_cast<int>(n + si);
+          }
+        }
+        float r, g, b;
+        if (win >= 0) {
+          if (win < static_cast<int>(n)) {
+            const float4 col = p.tri_color[win];
+            r = col.x; g = col.y; b = col.z;
+          } else {
+            const float4 sph = p.spheres[win - static_cast<int>(n)];
+            const V3 hp = {M::madd1(d[k].x, dist, o[k].x), M::madd1(d[k].y, dist, o[k].y),
+                           M::madd1(d[k].z, dist, o[k].z)};                 // Ray::point, Ray.cuh:41-44
+            const V3 nn = M::normalize(rtd::sub(hp, {sph.x, sph.y, sph.z}));
+            r = rtd::absf(nn.x); g = rtd::absf(nn.y); b = rtd::absf(nn.z);
+          }
+        } else {                                                    // :103, background (0.15,0.11,0.13)
+          if constexpr (FMA) {
+            r = __builtin_fmaf(d[k].x, 0.2f, 0.15f * 0.8f);
+            g = __builtin_fmaf(d[k].y, 0.2f, 0.11f * 0.8f);
+            b = __builtin_fmaf(d[k].z, 0.2f, 0.13f * 0.8f);
+          } else {
+            r = 0.15f * 0.8f + d[k].x * 0.2f;
+            g = 0.11f * 0.8f + d[k].y * 0.2f;
+            b = 0.13f * 0.8f + d[k].z * 0.2f;
+          }
+        }
+        ax += r; ay += g; az += b;                                  // :137
+      }
+    }
+  }
+
+  if (inside) {
+    p.counts[pix] += p.samples;                                     // :140
+    float4 acc = p.render[pix];
+    acc.x += ax; acc.y += ay; acc.z += az;                          // :141-143, alpha untouched (:144)
+    p.render[pix] = acc;
+    p.rng[0 * static_cast<size_t>(p.npix) + pix] = rng.d;           // :146
+    p.rng[1 * static_cast<size_t>(p.npix) + pix] = rng.v0;
+    p.rng[2 * static_cast<size_t>(p.npix) + pix] = rng.v1;
+    p.rng[3 * static_cast<size_t>(p.npix) + pix] = rng.v2;
+    p.rng[4 * static_cast<size_t>(p.npix) + pix] = rng.v3;
+    p.rng[5 * static_cast<size_t>(p.npix) + pix] = rng.v4;
+  }
+  if constexpr (STATS) {
+    if (lane == 0 && p.stats != nullptr) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        atomicAdd(p.stats + e, st_exit[e]);
+        atomicAdd(p.stats + 4 + e, st_skip[e]);
+      }
+      atomicAdd(p.stats + 8, st_bin[0]);
+      atomicAdd(p.stats + 9, st_bin[1]);
+    }
+  }
+}
+
+}  // namespace rtk

@@ -119,7 +119,7 @@ struct rt_tracer {
   uint32_t row0 = 0, rows = 0;      // owned band
   bool band_mode = false;
   uint64_t seed = 1;
-  bool fma = true, filter = true;
+  bool fma = true, filter = true, bin = true;
   uint32_t k_req = 0, chunk_req = 0;
 
   // device state
@@ -248,11 +248,11 @@ struct rt_tracer {
     for (uint32_t i = 0; i < iterations && !stopped; ++i) {
       rtk::TraceParams p = params(samples);
       last_k = K; last_chunk = p.chunk;
-      last_lds = rtk::trace_lds_bytes(p);
+      last_lds = rtk::trace_lds_bytes(p, bin);
       EventPair e = take_events();
       e.launches = 1;
       HIP_CHECK(hipEventRecord(e.a, stream));
-      HIP_CHECK(rtk::launch_trace(p, fma, filter, K, stream));
+      HIP_CHECK(rtk::launch_trace(p, fma, filter, bin, K, stream));
       HIP_CHECK(hipEventRecord(e.b, stream));
       { std::lock_guard<std::mutex> lk(time_mu); pending.push_back(e); }
       if (per_iteration_sync) { HIP_CHECK(hipEventSynchronize(e.b)); }    // :228
@@ -437,6 +437,7 @@ int rt_tracer_create_ex(const uint32_t imageSize[2], const float cameraPosition[
   t->seed = opt.use_time_seed ? static_cast<uint64_t>(static_cast<uint32_t>(time(nullptr))) : opt.seed;
   t->fma = opt.math_mode != RT_MATH_STRICT;
   t->filter = (opt.flags & RT_FLAG_NO_FILTER) == 0;
+  t->bin = (opt.flags & RT_FLAG_NO_BINNING) == 0;
   t->k_req = opt.samples_in_flight;
   t->chunk_req = opt.lds_chunk;
   Camera& c = t->cam;
@@ -627,20 +628,20 @@ int rt_tracer_trace_enqueue(rt_tracer* t, uint32_t iterationCount, uint32_t samp
   });
 }
 
-int rt_tracer_trace_stats(rt_tracer* t, uint32_t samples, uint64_t out[8]) {
+int rt_tracer_trace_stats(rt_tracer* t, uint32_t samples, uint64_t out[16]) {
   if (!t || !out) return RT_ERR_INVALID;
   std::lock_guard<std::mutex> lk(t->api_mu);
   return guarded(t, [&] {
     t->cancel_and_join();
     t->use_device();
-    DevBuf counters(8 * sizeof(unsigned long long));
-    HIP_CHECK(hipMemsetAsync(counters.p, 0, 8 * sizeof(unsigned long long), t->stream));
+    DevBuf counters(16 * sizeof(unsigned long long));
+    HIP_CHECK(hipMemsetAsync(counters.p, 0, 16 * sizeof(unsigned long long), t->stream));
     t->clear_accumulators();
     rtk::TraceParams p = t->params(samples);
     p.stats = counters.as<unsigned long long>();
-    HIP_CHECK(rtk::launch_trace(p, t->fma, t->filter, t->pick_k(samples), t->stream));
+    HIP_CHECK(rtk::launch_trace(p, t->fma, t->filter, t->bin, t->pick_k(samples), t->stream));
     HIP_CHECK(hipStreamSynchronize(t->stream));
-    HIP_CHECK(hipMemcpy(out, counters.p, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(out, counters.p, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   });
 }
 

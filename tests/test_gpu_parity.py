@@ -155,7 +155,7 @@ def test_filter_off_equals_filter_on(rt, orc):
 
 
 def test_lds_chunking_invariance(rt, orc):
-    g, o = run_pair(rt, orc, 40, 24, scene("rand300"), 2, 4, lds_chunk=64)   # 300 triangles -> 5 chunks
+    g, o = run_pair(rt, orc, 40, 24, scene("rand300"), 2, 4, lds_chunk=64, no_binning=True)   # 300 triangles -> 5 chunks
     assert g.Info()["lds_chunk"] == 64 and g.Info()["lds_bytes"] == 64 * 36
     assert_frame_equal(g, o)
 
@@ -280,3 +280,90 @@ def test_trace_enqueue_matches_trace(rt, orc):
     assert np.array_equal(h.Image(), g.Image())
     ms, n = h.KernelTime()
     assert n == 2 and ms > 0.0
+
+
+# ------------------------------------------------------------------ per-tile classification (BIN) vs full scan
+def _bin_pair(W, H, scn, it, spp, mode=0, **cam):
+    import raytracertest_amd as R
+    out = []
+    for no_binning in (False, True):
+        g = R.RayTracer((W, H), (0, 0, 0), cam.get("angles", (0.0, 0.0)), cam.get("fov", 70.0),
+                        cam.get("focal", 3.0), cam.get("aperture", 0.05), seed=cam.get("seed", 1),
+                        math_mode=mode, no_binning=no_binning)
+        assert g.UploadScene(scn)
+        g.Trace(it, spp, 0)
+        assert g.Wait()
+        out.append((g.RenderBuffer(), g.SampleCounts(), g.RngStates(), g.Image()))
+    a, b = out
+    bad = np.argwhere(u32(a[0]) != u32(b[0]))
+    assert bad.size == 0, "binning changed %d render values, first at %s" % (bad.shape[0], bad[0].tolist())
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    return a
+
+
+def _stress_scene(kind, n, seed):
+    from raytracertest_amd import scenes
+    rng = np.random.default_rng(seed)
+    if kind == "around_origin":      # triangles all around (and through) the lens: negative t, loose bounds
+        c = rng.uniform(-1.5, 1.5, (n, 1, 3))
+        t = c + rng.uniform(-0.6, 0.6, (n, 3, 3))
+    elif kind == "big_overlapping":  # every tile sees hundreds of candidates -> multi-round lists
+        c = np.concatenate([rng.uniform(-0.5, 0.5, (n, 1, 2)), rng.uniform(-9, -2, (n, 1, 1))], axis=2)
+        t = c + rng.uniform(-6, 6, (n, 3, 3)) * np.array([1, 1, 0.05])
+    elif kind == "grazing":          # nearly edge-on to the view direction: det ~ 0
+        c = np.concatenate([rng.uniform(-2, 2, (n, 1, 2)), rng.uniform(-8, -2, (n, 1, 1))], axis=2)
+        off = rng.uniform(-1, 1, (n, 3, 3))
+        off[:, :, 0] *= 1e-4         # flattened in x: planes contain the z axis direction
+        t = c + off
+    elif kind == "scales":           # tiny and huge triangles, far and near
+        s = 10.0 ** rng.uniform(-4, 3, (n, 1, 1))
+        c = rng.uniform(-1, 1, (n, 1, 3)) * s + np.array([0, 0, -3.0])
+        t = c + rng.uniform(-1, 1, (n, 3, 3)) * s
+    else:
+        raise KeyError(kind)
+    return scenes._tri_rows(t)
+
+
+@pytest.mark.parametrize("kind,n", [("around_origin", 400), ("big_overlapping", 700), ("grazing", 500), ("scales", 500)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_binning_equals_full_scan_stress(rt, kind, n, mode):
+    _bin_pair(72, 40, _stress_scene(kind, n, 11), 1, 6, mode=mode, aperture=0.08, focal=3.0)
+
+
+@pytest.mark.parametrize("cam", [dict(aperture=0.0, focal=3.0), dict(aperture=4.0, focal=10.0),
+                                 dict(aperture=0.3, focal=0.5, fov=120.0), dict(aperture=0.05, focal=3.0, angles=(0.4, 2.5)),
+                                 dict(aperture=-0.2, focal=-2.0), dict(aperture=0.05, focal=3.0, fov=5.0)])
+def test_binning_equals_full_scan_cameras(rt, cam):
+    from raytracertest_amd import scenes
+    _bin_pair(64, 48, scenes.random_triangles(1500, 99), 1, 5, **cam)
+    _bin_pair(40, 24, scene("cornell"), 2, 3, **cam)
+
+
+def test_binning_with_degenerate_and_nonfinite_triangles(rt):
+    from raytracertest_amd import scenes
+    scn = scenes.random_triangles(200, 5).copy()
+    t = scn.reshape(-1, 3, 4)
+    t[3, 1] = t[3, 0]                      # zero-area (two equal vertices)
+    t[7, :, :3] = t[7, 0, :3]              # a point
+    t[11, 2, 0] = np.nan
+    t[13, 1, 2] = np.inf
+    t[17, :, :3] *= 1e30
+    t[19, :, :3] *= 1e-30
+    a = _bin_pair(56, 32, scn, 1, 4)
+    # NaN/inf vertices never produce a hit in the reference arithmetic either; image stays finite
+    assert np.isfinite(a[0]).all()
+
+
+def test_binning_candidate_lists_are_short_on_the_bench_scenes(rt):
+    import raytracertest_amd as R
+    from raytracertest_amd import scenes
+    g = R.RayTracer((480, 270), (0, 0, 0), (0, 0), 70.0, 3.0, 0.05, seed=1)
+    g.UploadScene(scenes.cornell32())
+    st = g.TraceStats(4)
+    waves = (480 // 8) * ((270 + 7) // 8)
+    assert st["bin_rounds"] == waves                      # one classification per wave, list fits
+    assert st["bin_candidates"] / waves < 16              # of 32 triangles
+    g = R.RayTracer((480, 270), (0, 0, 0), (0, 0), 70.0, 3.0, 0.05, seed=1)
+    g.UploadScene(scenes.random_triangles(10000, 12345))
+    st = g.TraceStats(4)
+    assert st["bin_rounds"] <= 2 * waves and st["bin_candidates"] / st["bin_rounds"] < 200   # of 10 000
