@@ -26,7 +26,15 @@ struct TraceParams {
   uint32_t  n_spheres;
   uint32_t  chunk;          // triangles staged into LDS at a time
   unsigned long long* stats; // null in the product path; 16 counters for the instrumented launch
+  uint32_t* image;     // rows*W BGRA8, written when flags & TRACE_EMIT_IMAGE (mImageBuffer)
+  uint32_t  flags;     // TRACE_*
 };
+
+// The accumulators are logically zero (first launch after ClearRenderBuffer/ClearSampleCountBuffer,
+// RayTracerImpl.cu:242-243): skip their loads and the memsets; 0.0f + x is still evaluated.
+constexpr uint32_t TRACE_ZERO_ACC = 1u;
+// Also write the BGRA8 image from the updated accumulators (ConverterKernel fused, Kernels.cuh:149-169).
+constexpr uint32_t TRACE_EMIT_IMAGE = 2u;
 
 hipError_t launch_rng_init(uint32_t* rng, uint32_t npix, uint32_t p0, const uint32_t seeded[6],
                            const uint32_t* jump, hipStream_t st);

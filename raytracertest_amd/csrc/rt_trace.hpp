@@ -34,6 +34,9 @@ using rtd::V3;
 #define RT_TRACE_MIN_WAVES 4     // __launch_bounds__ 2nd argument: waves per SIMD the allocator must allow
                                  // (<= 128 VGPRs; measured C3 213 -> 193 us, C4 27.2 -> 24.3 ms vs the 136-VGPR build)
 #endif
+#ifndef RT_TRACE_WAVES
+#define RT_TRACE_WAVES(K) RT_TRACE_MIN_WAVES
+#endif
 #define RT_BIN_LIST 256u         // candidate records per wave in LDS (40 bytes each)
 
 // ------------------------------------------------------------------------------------
@@ -367,7 +370,7 @@ __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0,
 // Dynamic LDS: BIN ? 4 waves * RT_BIN_LIST * 40 bytes : min(n_tris, chunk) * 36 bytes.
 // ------------------------------------------------------------------------------------
 template <bool FMA, int K, bool FILTER, bool STATS, bool BIN>
-__global__ __launch_bounds__(256, RT_TRACE_MIN_WAVES) void trace_kernel(const TraceParams p) {
+__global__ __launch_bounds__(256, RT_TRACE_WAVES(K)) void trace_kernel(const TraceParams p) {
   using M = Math<FMA>;
   extern __shared__ float4 s_mem[];
 
@@ -385,6 +388,15 @@ __global__ __launch_bounds__(256, RT_TRACE_MIN_WAVES) void trace_kernel(const Tr
   rng.v2 = p.rng[3 * static_cast<size_t>(p.npix) + pix];
   rng.v3 = p.rng[4 * static_cast<size_t>(p.npix) + pix];
   rng.v4 = p.rng[5 * static_cast<size_t>(p.npix) + pix];
+
+  // accumulator read issued up front so that its latency hides under the tracing (the +=
+  // at the end then only waits for an already-finished load; measured C3 212 -> 197 us)
+  float4 acc_in = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  uint32_t cnt_in = 0u;
+  if (!(p.flags & TRACE_ZERO_ACC)) {                                // wave-uniform
+    acc_in = p.render[pix];
+    cnt_in = p.counts[pix];
+  }
 
   V3 po, pd;
   pinhole<FMA>(p, cxp, p.row0 + cyp, po, pd);
@@ -537,10 +549,15 @@ __global__ __launch_bounds__(256, RT_TRACE_MIN_WAVES) void trace_kernel(const Tr
   }
 
   if (inside) {
-    p.counts[pix] += p.samples;                                     // :140
-    float4 acc = p.render[pix];
+    const uint32_t cnt = cnt_in + p.samples;                        // :140
+    p.counts[pix] = cnt;
+    float4 acc = acc_in;
     acc.x += ax; acc.y += ay; acc.z += az;                          // :141-143, alpha untouched (:144)
     p.render[pix] = acc;
+    if (p.flags & TRACE_EMIT_IMAGE) {                               // fused rt::ConverterKernel, :164-168
+      const float c = static_cast<float>(cnt);
+      p.image[pix] = rtd::pack_color(255.0f * (acc.x / c), 255.0f * (acc.y / c), 255.0f * (acc.z / c));
+    }
     p.rng[0 * static_cast<size_t>(p.npix) + pix] = rng.d;           // :146
     p.rng[1 * static_cast<size_t>(p.npix) + pix] = rng.v0;
     p.rng[2 * static_cast<size_t>(p.npix) + pix] = rng.v1;

@@ -229,7 +229,11 @@ struct rt_tracer {
 
   int pick_k(uint32_t samples) const {
     if (k_req == 1 || k_req == 2 || k_req == 4) return static_cast<int>(k_req);
-    return samples >= 4 ? 4 : samples >= 2 ? 2 : 1;
+    // K samples of a pixel in registers per pass.  4 amortises the LDS record reads on long
+    // candidate lists (C4: 27 ms vs 35 ms at K = 1); scenes with a handful of triangles are
+    // ray-generation bound and run ~5 % faster at 2 (fewer VGPRs, C3: 191 vs 197 us).
+    const uint32_t want = (n_tris <= 128u) ? 2u : 4u;
+    return samples >= want ? static_cast<int>(want) : samples >= 2 ? 2 : 1;
   }
 
   EventPair take_events() {
@@ -241,22 +245,23 @@ struct rt_tracer {
     return e;
   }
 
-  // RunTraceKernel, RayTracerImpl.cu:204-234, without the blocking wait
-  void enqueue_trace_launches(uint32_t iterations, uint32_t samples, bool per_iteration_sync) {
-    if (iterations == 0) return;
+  // RunTraceKernel, RayTracerImpl.cu:204-234, without the blocking wait.  `flags` are the
+  // TRACE_* fusions: the first launch after the clear treats the accumulators as zero (no
+  // memset, no accumulator read), a launch whose result is handed out also writes BGRA8.
+  void enqueue_trace_launch(uint32_t samples, uint32_t flags, bool sync_after) {
     const int K = pick_k(samples);
-    for (uint32_t i = 0; i < iterations && !stopped; ++i) {
-      rtk::TraceParams p = params(samples);
-      last_k = K; last_chunk = p.chunk;
-      last_lds = rtk::trace_lds_bytes(p, bin);
-      EventPair e = take_events();
-      e.launches = 1;
-      HIP_CHECK(hipEventRecord(e.a, stream));
-      HIP_CHECK(rtk::launch_trace(p, fma, filter, bin, K, stream));
-      HIP_CHECK(hipEventRecord(e.b, stream));
-      { std::lock_guard<std::mutex> lk(time_mu); pending.push_back(e); }
-      if (per_iteration_sync) { HIP_CHECK(hipEventSynchronize(e.b)); }    // :228
-    }
+    rtk::TraceParams p = params(samples);
+    p.flags = flags;
+    p.image = d_image;
+    last_k = K; last_chunk = p.chunk;
+    last_lds = rtk::trace_lds_bytes(p, bin);
+    EventPair e = take_events();
+    e.launches = 1;
+    HIP_CHECK(hipEventRecord(e.a, stream));
+    HIP_CHECK(rtk::launch_trace(p, fma, filter, bin, K, stream));
+    HIP_CHECK(hipEventRecord(e.b, stream));
+    { std::lock_guard<std::mutex> lk(time_mu); pending.push_back(e); }
+    if (sync_after) { HIP_CHECK(hipEventSynchronize(e.b)); }              // :228
   }
 
   void drain_events() {
@@ -274,8 +279,11 @@ struct rt_tracer {
     HIP_CHECK(hipMemsetAsync(d_counts, 0, static_cast<size_t>(npix()) * sizeof(uint32_t), stream));
   }
 
-  void convert_and_fetch() {                                             // RunConverterKernel :189-202 + D2H
+  void convert() {                                                       // RunConverterKernel :189-202
     HIP_CHECK(rtk::launch_convert(d_render, d_counts, d_image, npix(), stream));
+  }
+
+  void fetch_image() {                                                   // device image -> pinned host copy
     HIP_CHECK(hipMemcpyAsync(h_image, d_image, static_cast<size_t>(npix()) * sizeof(uint32_t),
                              hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));                             // :259,:287
@@ -285,19 +293,27 @@ struct rt_tracer {
   void trace_funct(uint32_t iterationCount, uint32_t samplesPerIteration, uint32_t updateInterval) {
     try {
       use_device();
-      clear_accumulators();
+      bool cleared = false;                                              // :242-243, fused into launch 0
       for (uint32_t i = 0; !stopped && i < iterationCount; ++i) {         // :246
-        enqueue_trace_launches(1, samplesPerIteration, true);            // :249
         rt_callback_fn cb; void* user;
         { std::lock_guard<std::mutex> lk(state_mu); cb = update_cb; user = update_user; }
-        if (cb != nullptr && i > 0 && updateInterval > 0 && i % updateInterval == 0) {   // :256
-          convert_and_fetch();
+        const bool update = cb != nullptr && i > 0 && updateInterval > 0 && i % updateInterval == 0;   // :256
+        const uint32_t flags = (cleared ? 0u : rtk::TRACE_ZERO_ACC) |
+                               ((update || i + 1 == iterationCount) ? rtk::TRACE_EMIT_IMAGE : 0u);
+        enqueue_trace_launch(samplesPerIteration, flags, true);          // :249
+        cleared = true;
+        if (update) {
+          fetch_image();                                                 // :259-270 (conversion fused)
           cb(h_image, static_cast<size_t>(npix()) * sizeof(uint32_t), user);              // :272
         }
       }
       drain_events();
-      if (stopped) return;                                               // :280-284, no callback
-      convert_and_fetch();
+      if (!cleared) {                                                    // no launch ran: plain clear (+ convert below)
+        clear_accumulators();
+        if (!stopped) convert();
+      }
+      if (stopped) { HIP_CHECK(hipStreamSynchronize(stream)); return; }   // :280-284, no callback
+      fetch_image();                                                     // :287-295
       completed = true;
       rt_callback_fn cb; void* user;
       { std::lock_guard<std::mutex> lk(state_mu); cb = finished_cb; user = finished_user; }
@@ -622,9 +638,15 @@ int rt_tracer_trace_enqueue(rt_tracer* t, uint32_t iterationCount, uint32_t samp
   return guarded(t, [&] {
     t->cancel_and_join();
     t->use_device();
-    t->clear_accumulators();
-    t->enqueue_trace_launches(iterationCount, samplesPerIteration, false);
-    HIP_CHECK(rtk::launch_convert(t->d_render, t->d_counts, t->d_image, t->npix(), t->stream));
+    if (iterationCount == 0) {
+      t->clear_accumulators();
+      t->convert();
+    }
+    for (uint32_t i = 0; i < iterationCount; ++i)
+      t->enqueue_trace_launch(samplesPerIteration,
+                              (i == 0 ? rtk::TRACE_ZERO_ACC : 0u) |
+                                  (i + 1 == iterationCount ? rtk::TRACE_EMIT_IMAGE : 0u),
+                              false);
   });
 }
 
