@@ -67,8 +67,8 @@ typedef struct rt_options {
   uint64_t seed;               /* curand_init seed when use_time_seed == 0 */
   uint32_t flags;              /* RT_FLAG_* */
   uint32_t samples_in_flight;  /* samples of a pixel kept in registers per pass (1,2,4; 0 = auto) */
-  uint32_t lds_chunk;          /* triangles staged in LDS at a time (0 = auto) */
-  uint32_t reserved;
+  uint32_t lds_chunk;          /* full-scan path: triangles staged in LDS at a time (0 = auto) */
+  uint32_t bin_list;           /* binned path: candidate records per wave in LDS (0 = auto; multiple of 64) */
 } rt_options;
 
 /* ---- the reference's public methods, one to one -------------------------------------- */

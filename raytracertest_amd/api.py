@@ -44,7 +44,7 @@ class Options(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("full_height", C.c_uint32),
                 ("row_begin", C.c_uint32), ("use_time_seed", C.c_uint32), ("math_mode", C.c_uint32),
                 ("seed", C.c_uint64), ("flags", C.c_uint32), ("samples_in_flight", C.c_uint32),
-                ("lds_chunk", C.c_uint32), ("reserved", C.c_uint32)]
+                ("lds_chunk", C.c_uint32), ("bin_list", C.c_uint32)]
 
 
 CALLBACK = C.CFUNCTYPE(None, C.POINTER(C.c_uint32), C.c_size_t, C.c_void_p)
@@ -138,7 +138,7 @@ class RayTracer:
     def __init__(self, imageSize, cameraPosition=(0.0, 0.0, 0.0), cameraAngles=(0.0, 0.0), fov=70.0,
                  focalLength=10.0, aperture=4.0, *, seed=None, device=0, math_mode=MATH_FMA,
                  full_height=0, row_begin=0, no_filter=False, no_binning=False, samples_in_flight=0,
-                 lds_chunk=0):
+                 lds_chunk=0, bin_list=0):
         self._lib = load_library()
         self._h = C.c_void_p()
         self._cbs = {}
@@ -151,7 +151,7 @@ class RayTracer:
         opt.seed = 0 if seed is None else int(seed)
         opt.math_mode = math_mode
         opt.flags = (FLAG_NO_FILTER if no_filter else 0) | (FLAG_NO_BINNING if no_binning else 0)
-        opt.samples_in_flight, opt.lds_chunk = samples_in_flight, lds_chunk
+        opt.samples_in_flight, opt.lds_chunk, opt.bin_list = samples_in_flight, lds_chunk, bin_list
         rc = self._lib.rt_tracer_create_ex(_u32p(size), _f32p(np.array(cameraPosition, np.float32)),
                                            _f32p(np.array(cameraAngles, np.float32)), fov, focalLength,
                                            aperture, C.byref(opt), C.byref(self._h))

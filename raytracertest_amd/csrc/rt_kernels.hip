@@ -201,7 +201,7 @@ hipError_t launch_prep_triangles(bool fma, const float4* verts, uint32_t n, floa
 }
 
 uint32_t trace_lds_bytes(const TraceParams& p, bool bin) {
-  if (bin) return 4u * RT_BIN_LIST * 40u;
+  if (bin) return 4u * p.bin_list * 40u;
   const uint32_t staged = p.n_tris < p.chunk ? p.n_tris : p.chunk;
   return staged * 36u;
 }

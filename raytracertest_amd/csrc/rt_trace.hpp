@@ -37,7 +37,7 @@ using rtd::V3;
 #ifndef RT_TRACE_WAVES
 #define RT_TRACE_WAVES(K) RT_TRACE_MIN_WAVES
 #endif
-#define RT_BIN_LIST 256u         // candidate records per wave in LDS (40 bytes each)
+// candidate records per wave in LDS (40 bytes each): TraceParams::bin_list, a multiple of 64
 
 // ------------------------------------------------------------------------------------
 // Exact HitTriangle in the reference's operation order (Kernels.cuh:29-65) on a
@@ -367,7 +367,7 @@ __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0,
 
 // ------------------------------------------------------------------------------------
 // The trace kernel.  grid = (ceil(W/32), ceil(rows/8)), block = 256 threads.
-// Dynamic LDS: BIN ? 4 waves * RT_BIN_LIST * 40 bytes : min(n_tris, chunk) * 36 bytes.
+// Dynamic LDS: BIN ? 4 waves * bin_list * 40 bytes : min(n_tris, chunk) * 36 bytes.
 // ------------------------------------------------------------------------------------
 template <bool FMA, int K, bool FILTER, bool STATS, bool BIN>
 __global__ __launch_bounds__(256, RT_TRACE_WAVES(K)) void trace_kernel(const TraceParams p) {
@@ -422,9 +422,10 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES(K)) void trace_kernel(const Tra
   }
 
   // ---- per-wave candidate list (BIN == true) ---------------------------------------------
-  float4* const cA = s_mem + static_cast<size_t>(wave) * (2u * RT_BIN_LIST);               // 2 float4 per candidate
-  float* const cB = reinterpret_cast<float*>(s_mem + 4u * 2u * RT_BIN_LIST) + wave * RT_BIN_LIST;
-  int* const cI = reinterpret_cast<int*>(s_mem + 4u * 2u * RT_BIN_LIST) + 4u * RT_BIN_LIST + wave * RT_BIN_LIST;
+  const uint32_t L = p.bin_list;
+  float4* const cA = s_mem + static_cast<size_t>(wave) * (2u * L);                         // 2 float4 per candidate
+  float* const cB = reinterpret_cast<float*>(s_mem + 4u * 2u * L) + wave * L;
+  int* const cI = reinterpret_cast<int*>(s_mem + 4u * 2u * L) + 4u * L + wave * L;
   TileFamily fam;
   bool list_complete = false;       // the list in LDS covers the whole scene (classification done once)
   uint32_t list_count = 0;
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES(K)) void trace_kernel(const Tra
   // classify triangles [from, n) until the list is full; returns the first unclassified index
   auto classify = [&](uint32_t from) -> uint32_t {
     uint32_t count = 0, base = from;
-    while (base < n && count + 64u <= RT_BIN_LIST) {
+    while (base < n && count + 64u <= L) {
       const uint32_t tri = base + lane;
       const bool valid = tri < n;
       const uint32_t ti = valid ? tri : (n - 1u);

@@ -120,7 +120,7 @@ struct rt_tracer {
   bool band_mode = false;
   uint64_t seed = 1;
   bool fma = true, filter = true, bin = true;
-  uint32_t k_req = 0, chunk_req = 0;
+  uint32_t k_req = 0, chunk_req = 0, bin_list_req = 0;
 
   // device state
   hipStream_t stream = nullptr;
@@ -224,6 +224,11 @@ struct rt_tracer {
     p.spheres = d_spheres; p.n_spheres = n_spheres;
     p.chunk = chunk_req ? chunk_req : 1024u;
     if (p.chunk > 4096u) p.chunk = 4096u;                                // 144 KiB of the CU's 160 KiB LDS
+    // per-wave candidate list: whole (small) scene if it fits, else 256 records = 40 KiB per
+    // block -> 4 blocks per CU; 64 records = 10 KiB per block lets 8 blocks (32 waves) share a CU
+    uint32_t want = bin_list_req ? bin_list_req : ((n_tris + 63u) / 64u) * 64u;
+    want = ((want + 63u) / 64u) * 64u;
+    p.bin_list = want < 64u ? 64u : want > (bin_list_req ? 960u : 256u) ? (bin_list_req ? 960u : 256u) : want;
     return p;
   }
 
@@ -456,6 +461,7 @@ int rt_tracer_create_ex(const uint32_t imageSize[2], const float cameraPosition[
   t->bin = (opt.flags & RT_FLAG_NO_BINNING) == 0;
   t->k_req = opt.samples_in_flight;
   t->chunk_req = opt.lds_chunk;
+  t->bin_list_req = opt.bin_list;
   Camera& c = t->cam;
   for (int i = 0; i < 3; ++i) c.position[i] = cameraPosition ? cameraPosition[i] : 0.0f;
   c.angles[0] = cameraAngles[0]; c.angles[1] = cameraAngles[1];

@@ -17,7 +17,7 @@ import raytracertest_amd as R
 from raytracertest_amd import scenes
 cfg = dict(scenes.CONFIGS[%(config)r]); tris, sph = scenes.scene_for(%(config)r)
 g = R.RayTracer((cfg["width"], cfg["height"]), (0, 0, 0), cfg["angles"], cfg["fov"], cfg["focal"], cfg["aperture"],
-                seed=cfg["seed"], samples_in_flight=%(k)d, lds_chunk=%(chunk)d, no_filter=%(nofilter)r, no_binning=%(nobin)r)
+                seed=cfg["seed"], samples_in_flight=%(k)d, lds_chunk=%(chunk)d, no_filter=%(nofilter)r, no_binning=%(nobin)r, bin_list=%(binlist)d)
 if tris.shape[0]: g.UploadScene(tris)
 if sph.shape[0]: g.UploadSpheres(sph)
 for _ in range(%(warmup)d): g.TraceEnqueue(1, cfg["samples"])
@@ -40,7 +40,7 @@ def main():
     for v in a.variants:
         name, rest = v.split("=", 1)
         parts = rest.split(",")
-        opts = {"lib": parts[0], "k": 0, "chunk": 0, "nofilter": False, "nobin": False}
+        opts = {"lib": parts[0], "k": 0, "chunk": 0, "nofilter": False, "nobin": False, "binlist": 0}
         for p in parts[1:]:
             key, val = p.split("=")
             opts[key] = (val == "1") if key in ("nofilter", "nobin") else int(val)
@@ -51,7 +51,7 @@ def main():
             env = dict(os.environ)
             lib = o["lib"]
             env["RT_MI355X_LIB"] = lib if os.path.isabs(lib) else os.path.join(ROOT, "raytracertest_amd", "lib", lib)
-            code = CHILD % dict(root=ROOT, config=a.config, k=o["k"], chunk=o["chunk"], nofilter=o["nofilter"], nobin=o["nobin"],
+            code = CHILD % dict(root=ROOT, config=a.config, k=o["k"], chunk=o["chunk"], nofilter=o["nofilter"], nobin=o["nobin"], binlist=o["binlist"],
                                 warmup=a.warmup, steps=a.steps)
             out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
             if out.returncode != 0:
