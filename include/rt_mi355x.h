@@ -121,6 +121,12 @@ int  rt_tracer_upload_spheres(rt_tracer* t, const rt_float4* spheres, size_t cou
  * callbacks, no host synchronisation.  rt_tracer_sync waits for the stream. */
 int  rt_tracer_trace_enqueue(rt_tracer* t, uint32_t iterationCount, uint32_t samplesPerIteration);
 int  rt_tracer_sync(rt_tracer* t);
+/* One iteration of TraceFunct's loop as a building block for external drivers (the
+ * multi-GPU progressive path, raytracertest_amd/dist.py): enqueue ONE trace launch of
+ * `samples` spp.  clear_first != 0: the accumulators are cleared first (iteration 0,
+ * RayTracerImpl.cu:242-243); emit_image != 0: the BGRA8 image is refreshed too (an update or
+ * the last iteration, RayTracerImpl.cu:259-270,287-295).  No callbacks, no host sync. */
+int  rt_tracer_launch(rt_tracer* t, uint32_t samples, int clear_first, int emit_image);
 /* Sum of the trace-kernel durations (HIP events on the tracer's stream) and number of
  * trace-kernel launches since the last reset; reset_after != 0 clears both. */
 int  rt_tracer_kernel_time(rt_tracer* t, double* total_ms, uint64_t* launches, int reset_after);

@@ -656,6 +656,17 @@ int rt_tracer_trace_enqueue(rt_tracer* t, uint32_t iterationCount, uint32_t samp
   });
 }
 
+int rt_tracer_launch(rt_tracer* t, uint32_t samples, int clear_first, int emit_image) {
+  if (!t) return RT_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(t->api_mu);
+  return guarded(t, [&] {
+    t->cancel_and_join();
+    t->use_device();
+    t->enqueue_trace_launch(samples, (clear_first ? rtk::TRACE_ZERO_ACC : 0u) | (emit_image ? rtk::TRACE_EMIT_IMAGE : 0u),
+                            false);
+  });
+}
+
 int rt_tracer_trace_stats(rt_tracer* t, uint32_t samples, uint64_t out[16]) {
   if (!t || !out) return RT_ERR_INVALID;
   std::lock_guard<std::mutex> lk(t->api_mu);

@@ -48,6 +48,51 @@ def gather_tiles(tile, world, rank, group=None):
     return torch.cat([t[:r] for t, r in zip(out, all_rows)], dim=0)
 
 
+def update_due(i, update_interval, have_callback=True):
+    """The reference's update cadence, RayTracerImpl.cu:256."""
+    return have_callback and i > 0 and update_interval > 0 and i % update_interval == 0
+
+
+def progressive_trace(launch, tile, world, rank, iterations, samples, update_interval,
+                      on_update=None, on_finished=None, stop_requested=None, all_reduce_max=None):
+    """RayTracerImpl::TraceFunct (RayTracerImpl.cu:236-315) for a frame sharded in row bands.
+
+    Every rank runs the same iteration loop on its own band; at an update iteration and at
+    the end the BGRA8 tiles are gathered to rank 0, which fires the callbacks with the whole
+    frame -- the per-update hand-off of the reference (:259-272,:287-305) at multi-GPU scale.
+    Cancel granularity is one iteration, as in the reference (:248): rank 0's stop request is
+    agreed on by all ranks with a 1-element MAX all-reduce before each launch, so that no
+    rank leaves the loop (and its collectives) alone.  A stopped run fires no finished
+    callback (:280-284).  Returns True when the run completed.
+
+      launch(samples, clear_first, emit_image)  -> enqueue one launch on this rank's band
+      tile()                                    -> this rank's finished (rows, W) BGRA8 tensor
+      all_reduce_max(flag: int) -> int          -> max of `flag` over ranks (identity if world == 1)
+    """
+    if all_reduce_max is None:
+        def all_reduce_max(v):
+            return v
+    for i in range(iterations):
+        want_stop = 1 if (rank == 0 and stop_requested is not None and stop_requested()) else 0
+        if all_reduce_max(want_stop):
+            return False
+        upd = update_due(i, update_interval, on_update is not None)
+        launch(samples, i == 0, upd or i + 1 == iterations)
+        if upd:
+            frame = gather_tiles(tile(), world, rank)
+            if rank == 0 and on_update is not None:
+                on_update(frame)
+    want_stop = 1 if (rank == 0 and stop_requested is not None and stop_requested()) else 0
+    if all_reduce_max(want_stop):
+        return False
+    if iterations == 0:
+        return True
+    frame = gather_tiles(tile(), world, rank)
+    if rank == 0 and on_finished is not None:
+        on_finished(frame)
+    return True
+
+
 class RowBandJob:
     """One rank's share of a frame: a tracer on its band + the tile gather.
 
@@ -95,6 +140,39 @@ class RowBandJob:
             # hipMemcpyAsync on the tracer's stream + stream sync, then RCCL on torch's stream
             self.tracer.CopyToDevice(BUF_IMAGE, self.image_t.data_ptr(), self.image_t.numel() * 4)
             self.frame = gather_tiles(self.image_t, self.world, self.rank)
+
+    def _tile(self):
+        """Finished BGRA8 band as a torch tensor ready for the collective (host-syncs the tracer)."""
+        from .api import BUF_IMAGE
+        if self.world == 1:
+            import torch
+            return torch.from_numpy(self.tracer.Image().view(np.int32))
+        self.tracer.CopyToDevice(BUF_IMAGE, self.image_t.data_ptr(), self.image_t.numel() * 4)
+        return self.image_t
+
+    def trace_progressive(self, iterations, samples, update_interval, on_update=None, on_finished=None,
+                          stop_requested=None, have_update_callback=None):
+        """Multi-GPU Trace with the reference's callback cadence; callbacks run on rank 0 with
+        the gathered (full rows, W) frame.  `have_update_callback` must be the same on every
+        rank (defaults to: rank 0 passes on_update)."""
+        flag = on_update is not None if have_update_callback is None else have_update_callback
+        if self.world > 1 and have_update_callback is None:
+            flag = bool(self._all_reduce_max(1 if on_update is not None else 0))
+        def launch(spp, clear_first, emit):
+            self.tracer.Launch(spp, clear_first, emit)
+        ok = progressive_trace(launch, self._tile, self.world, self.rank, iterations, samples, update_interval,
+                               on_update=on_update if self.rank == 0 else (None if not flag else (lambda f: None)),
+                               on_finished=on_finished, stop_requested=stop_requested,
+                               all_reduce_max=self._all_reduce_max)
+        self.tracer.Sync()
+        return ok
+
+    def _all_reduce_max(self, v):
+        if self.world == 1:
+            return v
+        t = self.torch.tensor([int(v)], dtype=self.torch.int32, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return int(t.item())
 
     def finish(self):
         self.tracer.Sync()

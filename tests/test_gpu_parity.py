@@ -367,3 +367,25 @@ def test_binning_candidate_lists_are_short_on_the_bench_scenes(rt):
     g.UploadScene(scenes.random_triangles(10000, 12345))
     st = g.TraceStats(4)
     assert st["bin_rounds"] <= 2 * waves and st["bin_candidates"] / st["bin_rounds"] < 200   # of 10 000
+
+
+def test_launch_building_block_and_progressive_driver(rt, orc):
+    """rt_tracer_launch + dist.progressive_trace on one GPU == rt_tracer_trace == oracle."""
+    import raytracertest_amd as R
+    from raytracertest_amd import scenes
+    from raytracertest_amd.dist import RowBandJob
+    cfg = dict(width=48, height=28, iterations=1, samples=2, angles=(0.0, 0.0), fov=70.0, focal=3.0, aperture=0.05, seed=1)
+    job = RowBandJob(cfg, scenes.cornell32(), np.zeros((0, 4), np.float32))
+    updates, finished = [], []
+    ok = job.trace_progressive(7, 2, 3, on_update=lambda f: updates.append(f.numpy().view(np.uint32).copy()),
+                               on_finished=lambda f: finished.append(f.numpy().view(np.uint32).copy()))
+    assert ok and len(updates) == 2 and len(finished) == 1
+    o = orc.OracleTracer(48, 28, (0.0, 0.0), 70.0, 3.0, 0.05, seed=1, nthreads=4)
+    o.upload_scene(scenes.cornell32())
+    o.trace(7, 2)
+    assert np.array_equal(finished[0], o.image) and np.array_equal(job.tracer.RenderBuffer().view(np.uint32), o.render.view(np.uint32))
+    stop = {"n": 0}
+    ok = job.trace_progressive(50, 1, 2, on_update=lambda f: stop.__setitem__("n", stop["n"] + 1),
+                               on_finished=lambda f: finished.append(None), stop_requested=lambda: stop["n"] >= 2)
+    assert not ok and len(finished) == 1 and int(job.tracer.SampleCounts().max()) == 5    # launches 0..4, then agreed stop
+    job.close()
