@@ -42,6 +42,9 @@ extern "C" {
 #define RT_FLAG_NO_BINNING 2u  /* disable the per-tile triangle classification: every ray scans the whole
                                   list from block-staged LDS chunks (debug / parity tests / A-B) */
 
+#define RT_FLAG_NEAREST_HIT 4u  /* hit selection extension: keep the nearest hit with t > 0 instead of the
+                                  reference's farthest hit incl. negative t (Kernels.cuh:73,84).  Not the default. */
+
 #define RT_BUF_RENDER      0   /* rows*W*4 float  RGBA accumulators   (mRenderBuffer)      */
 #define RT_BUF_COUNTS      1   /* rows*W   uint32 sample counts       (mSampleCountBuffer) */
 #define RT_BUF_IMAGE       2   /* rows*W   uint32 BGRA8               (mImageBuffer)       */
@@ -103,6 +106,15 @@ void rt_tracer_rotate_camera(rt_tracer* t, const float angles[2]);
  * triangle, .w ignored; count < 3 or count % 3 != 0 is rejected and the previous scene
  * kept (RayTracerImpl.cu:121-125). */
 int  rt_tracer_upload_scene(rt_tracer* t, const rt_float4* hostData, size_t count);
+/* Same scene in the layout the reference's notes plan for the GPU (Documentation/gpu.meshes.txt:16-17):
+ * per triangle v0, e0 = v1 - v0, e1 = v2 - v0, each .w free for a packed vertex normal
+ * (rt_pack_normal).  With e0/e1 computed in fp32 the result equals rt_tracer_upload_scene. */
+int  rt_tracer_upload_scene_edges(rt_tracer* t, const rt_float4* hostData, size_t count);
+/* Corrected form of the reference's experimental normal packing (UnitTests/NormalPackingTest.cpp:10-23):
+ * three components in [-1,1] as 8-bit fields in the fraction of one float.  unpack(pack(n)) == n for
+ * every n whose components are multiples of 1/127. */
+float rt_pack_normal(const float n[3]);
+void  rt_unpack_normal(float packed, float n[3]);
 /* RayTracer::SetUpdateCallback / SetFinishedCallback, RayTracer.h:36-37. */
 void rt_tracer_set_update_callback(rt_tracer* t, rt_callback_fn fn, void* user);
 void rt_tracer_set_finished_callback(rt_tracer* t, rt_callback_fn fn, void* user);

@@ -91,6 +91,8 @@ typedef struct orc_scene {
   uint32_t     n_tris;
   const float* spheres;  /* n_spheres * 4 floats: centre xyz, radius (build-defined)      */
   uint32_t     n_spheres;
+  int32_t      hit_mode;  /* 0: reference rule (farthest hit, negative t accepted, Kernels.cuh:73,84);
+                             1: nearest hit with t > 0 (build-defined extension) */
 } orc_scene;
 
 /* A frame is a row band [row0, row0+rows) of a W x H image.  Buffers hold the band only:

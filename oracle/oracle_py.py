@@ -33,7 +33,7 @@ class Camera(C.Structure):
 
 class Scene(C.Structure):
     _fields_ = [("tris", C.POINTER(C.c_float)), ("n_tris", C.c_uint32),
-                ("spheres", C.POINTER(C.c_float)), ("n_spheres", C.c_uint32)]
+                ("spheres", C.POINTER(C.c_float)), ("n_spheres", C.c_uint32), ("hit_mode", C.c_int32)]
 
 
 class Frame(C.Structure):
@@ -172,11 +172,11 @@ class OracleTracer:
     :105-117 (camera), :119-177 (UploadScene)."""
 
     def __init__(self, width, height, angles=(0.0, 0.0), fov_deg=70.0, focal=10.0, aperture=4.0,
-                 seed=1, row0=0, rows=None, contract=FMA, nthreads=1):
+                 seed=1, row0=0, rows=None, contract=FMA, nthreads=1, hit_mode=0):
         self.W, self.H = int(width), int(height)
         self.row0 = int(row0)
         self.rows = int(self.H - self.row0 if rows is None else rows)
-        self.contract, self.nthreads, self.seed = contract, nthreads, seed
+        self.contract, self.nthreads, self.seed, self.hit_mode = contract, nthreads, seed, hit_mode
         self.cam = camera(angles, fov_deg, focal, aperture)
         self.tris = np.zeros((0, 12), np.float32)
         self.spheres = np.zeros((0, 4), np.float32)
@@ -207,7 +207,7 @@ class OracleTracer:
         lib().orc_camera_rotate(C.byref(self.cam), _fp(_f32(dangles)))
 
     def _scene(self):
-        return Scene(_fp(self.tris), self.tris.shape[0], _fp(self.spheres), self.spheres.shape[0])
+        return Scene(_fp(self.tris), self.tris.shape[0], _fp(self.spheres), self.spheres.shape[0], self.hit_mode)
 
     def launch(self, samples):
         sc = self._scene()

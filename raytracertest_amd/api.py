@@ -19,6 +19,7 @@ _LIB_PATH = os.environ.get("RT_MI355X_LIB") or os.path.join(_HERE, "lib", "librt
 MATH_FMA, MATH_STRICT = 0, 1
 FLAG_NO_FILTER = 1
 FLAG_NO_BINNING = 2
+FLAG_NEAREST_HIT = 4
 BUF_RENDER, BUF_COUNTS, BUF_IMAGE, BUF_RNG = 0, 1, 2, 3
 
 # every symbol include/rt_mi355x.h declares (checked by tests/test_abi.py)
@@ -27,7 +28,8 @@ ABI_SYMBOLS = [
     "rt_tracer_stop", "rt_tracer_resize", "rt_tracer_set_camera_parameters",
     "rt_tracer_rotate_camera", "rt_tracer_upload_scene", "rt_tracer_set_update_callback",
     "rt_tracer_set_finished_callback", "rt_tracer_wait", "rt_tracer_set_seed",
-    "rt_tracer_upload_spheres", "rt_tracer_trace_enqueue", "rt_tracer_sync", "rt_tracer_trace_stats", "rt_tracer_launch",
+    "rt_tracer_upload_spheres", "rt_tracer_trace_enqueue", "rt_tracer_sync", "rt_tracer_trace_stats", "rt_tracer_launch", "rt_tracer_upload_scene_edges", "rt_pack_normal",
+    "rt_unpack_normal",
     "rt_tracer_kernel_time", "rt_tracer_read_buffer", "rt_tracer_copy_buffer_to_device",
     "rt_tracer_device_pointer", "rt_tracer_buffer_bytes", "rt_tracer_info",
     "rt_tracer_last_error", "rt_last_error", "rt_device_count", "rt_version",
@@ -82,6 +84,11 @@ def load_library():
         L.rt_tracer_rotate_camera.argtypes = [vp, f32p]
         L.rt_tracer_rotate_camera.restype = None
         L.rt_tracer_upload_scene.argtypes = [vp, vp, C.c_size_t]
+        L.rt_tracer_upload_scene_edges.argtypes = [vp, vp, C.c_size_t]
+        L.rt_pack_normal.argtypes = [f32p]
+        L.rt_pack_normal.restype = C.c_float
+        L.rt_unpack_normal.argtypes = [C.c_float, f32p]
+        L.rt_unpack_normal.restype = None
         L.rt_tracer_set_update_callback.argtypes = [vp, CALLBACK, vp]
         L.rt_tracer_set_update_callback.restype = None
         L.rt_tracer_set_finished_callback.argtypes = [vp, CALLBACK, vp]
@@ -138,7 +145,7 @@ class RayTracer:
 
     def __init__(self, imageSize, cameraPosition=(0.0, 0.0, 0.0), cameraAngles=(0.0, 0.0), fov=70.0,
                  focalLength=10.0, aperture=4.0, *, seed=None, device=0, math_mode=MATH_FMA,
-                 full_height=0, row_begin=0, no_filter=False, no_binning=False, samples_in_flight=0,
+                 full_height=0, row_begin=0, no_filter=False, no_binning=False, nearest_hit=False, samples_in_flight=0,
                  lds_chunk=0, bin_list=0):
         self._lib = load_library()
         self._h = C.c_void_p()
@@ -151,7 +158,8 @@ class RayTracer:
         opt.use_time_seed = 1 if seed is None else 0          # Random.cu:45 when no seed is given
         opt.seed = 0 if seed is None else int(seed)
         opt.math_mode = math_mode
-        opt.flags = (FLAG_NO_FILTER if no_filter else 0) | (FLAG_NO_BINNING if no_binning else 0)
+        opt.flags = ((FLAG_NO_FILTER if no_filter else 0) | (FLAG_NO_BINNING if no_binning else 0) |
+                     (FLAG_NEAREST_HIT if nearest_hit else 0))
         opt.samples_in_flight, opt.lds_chunk, opt.bin_list = samples_in_flight, lds_chunk, bin_list
         rc = self._lib.rt_tracer_create_ex(_u32p(size), _f32p(np.array(cameraPosition, np.float32)),
                                            _f32p(np.array(cameraAngles, np.float32)), fov, focalLength,
@@ -184,6 +192,15 @@ class RayTracer:
         without raising (RayTracerImpl.cu:121-125); returns False in that case."""
         a = np.ascontiguousarray(hostData, np.float32).reshape(-1, 4)
         rc = self._lib.rt_tracer_upload_scene(self._h, a.ctypes.data, a.shape[0])
+        if rc == 1:
+            return False
+        self._check(rc)
+        return True
+
+    def UploadSceneEdges(self, hostData):
+        """(3N, 4) float32 in the v0, e0, e1 layout of Documentation/gpu.meshes.txt:16-17."""
+        a = np.ascontiguousarray(hostData, np.float32).reshape(-1, 4)
+        rc = self._lib.rt_tracer_upload_scene_edges(self._h, a.ctypes.data, a.shape[0])
         if rc == 1:
             return False
         self._check(rc)

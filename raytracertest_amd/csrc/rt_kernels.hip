@@ -57,8 +57,11 @@ __global__ __launch_bounds__(256) void rng_init_kernel(uint32_t* __restrict__ rn
 //   tri_a[2i+1] = (e1.y, e1.z, v0.x, v0.y)      (two ds_read_b128, wave-uniform)
 //   tri_b[i]    = v0.z                          stage B adds one ds_read_b32
 // ------------------------------------------------------------------------------------
+// `edges`: the input is already in the v0, e0 = v1-v0, e1 = v2-v0 layout of
+// Documentation/gpu.meshes.txt:16-17 (no subtraction here; .w = packed vertex normals, kept
+// by the caller, unused by the reference's flat shading).
 template <bool FMA>
-__global__ __launch_bounds__(256) void prep_triangles_kernel(const float4* __restrict__ verts, uint32_t n,
+__global__ __launch_bounds__(256) void prep_triangles_kernel(const float4* __restrict__ verts, uint32_t n, bool edges,
                                                               float4* __restrict__ tri_a,
                                                               float* __restrict__ tri_b,
                                                               float4* __restrict__ color) {
@@ -66,8 +69,8 @@ __global__ __launch_bounds__(256) void prep_triangles_kernel(const float4* __res
   if (i >= n) return;
   const float4 a = verts[3 * i + 0], b = verts[3 * i + 1], c = verts[3 * i + 2];
   const V3 v0 = {a.x, a.y, a.z};
-  const V3 e1 = rtd::sub({b.x, b.y, b.z}, v0);
-  const V3 e2 = rtd::sub({c.x, c.y, c.z}, v0);
+  const V3 e1 = edges ? V3{b.x, b.y, b.z} : rtd::sub({b.x, b.y, b.z}, v0);
+  const V3 e2 = edges ? V3{c.x, c.y, c.z} : rtd::sub({c.x, c.y, c.z}, v0);
   tri_a[2 * i + 0] = make_float4(e2.x, e2.y, e2.z, e1.x);
   tri_a[2 * i + 1] = make_float4(e1.y, e1.z, v0.x, v0.y);
   tri_b[i] = v0.z;
@@ -192,11 +195,11 @@ hipError_t launch_rng_init(uint32_t* rng, uint32_t npix, uint32_t p0, const uint
   return hipGetLastError();
 }
 
-hipError_t launch_prep_triangles(bool fma, const float4* verts, uint32_t n, float4* tri_a, float* tri_b,
+hipError_t launch_prep_triangles(bool fma, bool edges, const float4* verts, uint32_t n, float4* tri_a, float* tri_b,
                                  float4* color, hipStream_t st) {
   if (n == 0) return hipSuccess;
-  if (fma) hipLaunchKernelGGL(prep_triangles_kernel<true>, dim3(cdiv(n, 256)), dim3(256), 0, st, verts, n, tri_a, tri_b, color);
-  else hipLaunchKernelGGL(prep_triangles_kernel<false>, dim3(cdiv(n, 256)), dim3(256), 0, st, verts, n, tri_a, tri_b, color);
+  if (fma) hipLaunchKernelGGL(prep_triangles_kernel<true>, dim3(cdiv(n, 256)), dim3(256), 0, st, verts, n, edges, tri_a, tri_b, color);
+  else hipLaunchKernelGGL(prep_triangles_kernel<false>, dim3(cdiv(n, 256)), dim3(256), 0, st, verts, n, edges, tri_a, tri_b, color);
   return hipGetLastError();
 }
 

@@ -36,10 +36,12 @@ struct TraceParams {
 constexpr uint32_t TRACE_ZERO_ACC = 1u;
 // Also write the BGRA8 image from the updated accumulators (ConverterKernel fused, Kernels.cuh:149-169).
 constexpr uint32_t TRACE_EMIT_IMAGE = 2u;
+// Hit selection: keep the nearest t > 0 instead of the reference's farthest t (build-defined extension).
+constexpr uint32_t TRACE_NEAREST_HIT = 4u;
 
 hipError_t launch_rng_init(uint32_t* rng, uint32_t npix, uint32_t p0, const uint32_t seeded[6],
                            const uint32_t* jump, hipStream_t st);
-hipError_t launch_prep_triangles(bool fma, const float4* verts, uint32_t n, float4* tri_a, float* tri_b,
+hipError_t launch_prep_triangles(bool fma, bool edges, const float4* verts, uint32_t n, float4* tri_a, float* tri_b,
                                  float4* color, hipStream_t st);
 uint32_t trace_lds_bytes(const TraceParams& p, bool bin);
 // bin: per-tile triangle classification + per-wave LDS candidate lists (rt_trace.hpp);

@@ -143,7 +143,7 @@ __device__ __forceinline__ void get_ray(const TraceParams& p, V3 focal, Rng& rng
 template <bool FMA, int K, bool FILTER, bool STATS, class GetB>
 __device__ __forceinline__ void test_triangle(const float4 A0, const float4 A1, GetB get_v0z, int tri_index,
                                               const V3 (&o)[K], const V3 (&d)[K], float (&best_t)[K],
-                                              int (&best_i)[K], bool counted_lane, uint32_t valid_k,
+                                              int (&best_i)[K], bool nearest, bool counted_lane, uint32_t valid_k,
                                               unsigned long long (&st_exit)[4],
                                               unsigned long long (&st_skip)[4]) {
   using M = Math<FMA>;
@@ -156,7 +156,7 @@ __device__ __forceinline__ void test_triangle(const float4 A0, const float4 A1, 
       float t = 0.0f, u = 0.0f, v = 0.0f;
       int stage;
       const bool h = hit_triangle_exact<FMA>(o[k], d[k], v0, e1, e2, RT_EPS, t, u, v, stage);
-      if (h && best_t[k] < t) {                                    // :84
+      if (h && (nearest ? (t > 0.0f && t < best_t[k]) : best_t[k] < t)) {   // :84 (or nearest-hit extension)
         best_t[k] = t;
         best_i[k] = tri_index;
       }
@@ -222,7 +222,8 @@ __device__ __forceinline__ void test_triangle(const float4 A0, const float4 A1, 
         const float v = V[k] * inv;                                // :57
         const float t = M::dot(e2, qv[k]) * inv;                   // :63
         const bool miss = (det[k] < RT_EPS) | (u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f);
-        const bool upd = (!miss) & (best_t[k] < t);                // :84
+        const bool closer = nearest ? ((t > 0.0f) & (t < best_t[k])) : (best_t[k] < t);   // :84 / nearest-hit extension
+        const bool upd = (!miss) & closer;
         best_t[k] = upd ? t : best_t[k];
         best_i[k] = upd ? tri_index : best_i[k];
       }
@@ -403,6 +404,9 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES(K)) void trace_kernel(const Tra
   const V3 focal = focal_point<FMA>(p, pd);
 
   const uint32_t n = p.n_tris;
+  // false: the reference's rule (keep the farthest t, negative t accepted, Kernels.cuh:73,84);
+  // true: build-defined extension, keep the nearest t > 0.  Wave-uniform.
+  const bool nearest = (p.flags & TRACE_NEAREST_HIT) != 0u;
   float ax = 0.0f, ay = 0.0f, az = 0.0f;                           // accu, :133
   unsigned long long st_exit[4] = {0, 0, 0, 0};                    // STATS: lane-tests by exit point
   unsigned long long st_skip[4] = {0, 0, 0, 0};                    // STATS: wave-triangles skipped after A/B/C, reaching D
@@ -471,7 +475,7 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES(K)) void trace_kernel(const Tra
     for (int k = 0; k < K; ++k) {
       if (static_cast<uint32_t>(k) < valid_k) get_ray<FMA>(p, focal, rng, o[k], d[k]);   // :136
       else { o[k] = po; d[k] = pd; }                               // padding ray, result discarded
-      best_t[k] = -FLT_MAX;                                        // :73
+      best_t[k] = nearest ? FLT_MAX : -FLT_MAX;                    // :73
       best_i[k] = -1;
     }
 
@@ -486,7 +490,7 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES(K)) void trace_kernel(const Tra
         for (uint32_t j = 0; j < list_count; ++j) {                // ascending triangle order
           const float4 A0 = cA[2u * j], A1 = cA[2u * j + 1u];
           test_triangle<FMA, K, FILTER, STATS>(A0, A1, [&] { return cB[j]; }, cI[j], o, d, best_t, best_i,
-                                               inside, valid_k, st_exit, st_skip);
+                                               nearest, inside, valid_k, st_exit, st_skip);
         }
         base = next;
         if (!list_complete) __builtin_amdgcn_wave_barrier();       // list is rewritten by the next round
@@ -503,7 +507,7 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES(K)) void trace_kernel(const Tra
         for (uint32_t j = 0; j < cn; ++j) {                        // :75, ascending order
           const float4 A0 = sA[2u * j], A1 = sA[2u * j + 1u];
           test_triangle<FMA, K, FILTER, STATS>(A0, A1, [&] { return sB[j]; }, static_cast<int>(c0 + j), o, d,
-                                               best_t, best_i, inside, valid_k, st_exit, st_skip);
+                                               best_t, best_i, nearest, inside, valid_k, st_exit, st_skip);
         }
       }
     }
@@ -516,7 +520,7 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES(K)) void trace_kernel(const Tra
         int win = best_i[k];
         for (uint32_t si = 0; si < p.n_spheres; ++si) {
           float t = 0.0f;
-          if (hit_sphere<FMA>(o[k], d[k], p.spheres[si], t) && dist < t) {
+          if (hit_sphere<FMA>(o[k], d[k], p.spheres[si], t) && (nearest ? (t > 0.0f && t < dist) : dist < t)) {
             dist = t;
             win = static_cast<int>(n + si);
           }

@@ -8,6 +8,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -119,7 +120,7 @@ struct rt_tracer {
   uint32_t row0 = 0, rows = 0;      // owned band
   bool band_mode = false;
   uint64_t seed = 1;
-  bool fma = true, filter = true, bin = true;
+  bool fma = true, filter = true, bin = true, nearest_hit = false;
   uint32_t k_req = 0, chunk_req = 0, bin_list_req = 0;
 
   // device state
@@ -256,7 +257,7 @@ struct rt_tracer {
   void enqueue_trace_launch(uint32_t samples, uint32_t flags, bool sync_after) {
     const int K = pick_k(samples);
     rtk::TraceParams p = params(samples);
-    p.flags = flags;
+    p.flags = flags | (nearest_hit ? rtk::TRACE_NEAREST_HIT : 0u);
     p.image = d_image;
     last_k = K; last_chunk = p.chunk;
     last_lds = rtk::trace_lds_bytes(p, bin);
@@ -459,6 +460,7 @@ int rt_tracer_create_ex(const uint32_t imageSize[2], const float cameraPosition[
   t->fma = opt.math_mode != RT_MATH_STRICT;
   t->filter = (opt.flags & RT_FLAG_NO_FILTER) == 0;
   t->bin = (opt.flags & RT_FLAG_NO_BINNING) == 0;
+  t->nearest_hit = (opt.flags & RT_FLAG_NEAREST_HIT) != 0;
   t->k_req = opt.samples_in_flight;
   t->chunk_req = opt.lds_chunk;
   t->bin_list_req = opt.bin_list;
@@ -570,7 +572,7 @@ void rt_tracer_rotate_camera(rt_tracer* t, const float angles[2]) {      // :114
   t->cam.transform();
 }
 
-int rt_tracer_upload_scene(rt_tracer* t, const rt_float4* hostData, size_t count) {
+static int upload_scene_impl(rt_tracer* t, const rt_float4* hostData, size_t count, bool edges) {
   if (!t) return RT_ERR_INVALID;
   if (!hostData || count < 3 || count % 3 != 0) {                        // :121-125
     t->set_error(fmt("UploadScene got invalid triangle list. Size = %zu", count));
@@ -591,11 +593,37 @@ int rt_tracer_upload_scene(rt_tracer* t, const rt_float4* hostData, size_t count
     HIP_CHECK(hipMalloc(&t->d_tri_b, static_cast<size_t>(n) * sizeof(float)));
     HIP_CHECK(hipMalloc(&t->d_tri_color, static_cast<size_t>(n) * sizeof(float4)));
     HIP_CHECK(hipMemcpyAsync(verts.p, hostData, count * sizeof(float4), hipMemcpyHostToDevice, t->stream));
-    HIP_CHECK(rtk::launch_prep_triangles(t->fma, verts.as<float4>(), n, t->d_tri, t->d_tri_b,
+    HIP_CHECK(rtk::launch_prep_triangles(t->fma, edges, verts.as<float4>(), n, t->d_tri, t->d_tri_b,
                                          t->d_tri_color, t->stream));
     HIP_CHECK(hipStreamSynchronize(t->stream));
     t->n_tris = n;
   });
+}
+
+int rt_tracer_upload_scene(rt_tracer* t, const rt_float4* hostData, size_t count) {
+  return upload_scene_impl(t, hostData, count, false);
+}
+
+int rt_tracer_upload_scene_edges(rt_tracer* t, const rt_float4* hostData, size_t count) {
+  return upload_scene_impl(t, hostData, count, true);
+}
+
+// Corrected form of the reference's experimental normal packing (UnitTests/NormalPackingTest.cpp:10-23,
+// Documentation/gpu.meshes.txt:20-33): three 8-bit components in the 24-bit fraction of one float.
+float rt_pack_normal(const float n[3]) {
+  return floorf(n[0] * 127.0f + 127.5f) / 256.0f + floorf(n[1] * 127.0f + 127.5f) / 65536.0f +
+         floorf(n[2] * 127.0f + 127.5f) / 16777216.0f;
+}
+
+void rt_unpack_normal(float packed, float n[3]) {
+  // byte k sits at bits 2^-8(k+1): shift by 1, 256, 65536 (the reference's test multiplies
+  // by 1, 65536, 16777216, which does not invert pack)
+  const float m[3] = {1.0f, 256.0f, 65536.0f};
+  for (int i = 0; i < 3; ++i) {
+    const float s = packed * m[i];
+    const float frac = s - floorf(s);
+    n[i] = floorf(frac * 256.0f) / 127.0f - 1.0f;
+  }
 }
 
 int rt_tracer_upload_spheres(rt_tracer* t, const rt_float4* spheres, size_t count) {
@@ -678,6 +706,7 @@ int rt_tracer_trace_stats(rt_tracer* t, uint32_t samples, uint64_t out[16]) {
     t->clear_accumulators();
     rtk::TraceParams p = t->params(samples);
     p.stats = counters.as<unsigned long long>();
+    p.flags = t->nearest_hit ? rtk::TRACE_NEAREST_HIT : 0u;
     HIP_CHECK(rtk::launch_trace(p, t->fma, t->filter, t->bin, t->pick_k(samples), t->stream));
     HIP_CHECK(hipStreamSynchronize(t->stream));
     HIP_CHECK(hipMemcpy(out, counters.p, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
