@@ -156,6 +156,11 @@ int  rt_tracer_trace_stats(rt_tracer* t, uint32_t samples, uint64_t out[16]);
 /* Copy one of the tracer's device buffers to host memory / to another device pointer. */
 int  rt_tracer_read_buffer(rt_tracer* t, int which, void* dst, size_t bytes);
 int  rt_tracer_copy_buffer_to_device(rt_tracer* t, int which, void* dst_device, size_t bytes);
+/* Same copy without the host synchronisation, and the tracer's HIP stream (a hipStream_t) so
+ * that a driver can order its own work (e.g. the RCCL tile gather on another stream) behind it
+ * with events instead of blocking the host. */
+int  rt_tracer_copy_buffer_to_device_async(rt_tracer* t, int which, void* dst_device, size_t bytes);
+void* rt_tracer_stream(rt_tracer* t);
 void* rt_tracer_device_pointer(rt_tracer* t, int which);
 size_t rt_tracer_buffer_bytes(rt_tracer* t, int which);
 /* Launch geometry actually used: out[0]=K, out[1]=lds_chunk, out[2]=dynamic LDS bytes,

@@ -30,7 +30,8 @@ ABI_SYMBOLS = [
     "rt_tracer_set_finished_callback", "rt_tracer_wait", "rt_tracer_set_seed",
     "rt_tracer_upload_spheres", "rt_tracer_trace_enqueue", "rt_tracer_sync", "rt_tracer_trace_stats", "rt_tracer_launch", "rt_tracer_upload_scene_edges", "rt_pack_normal",
     "rt_unpack_normal",
-    "rt_tracer_kernel_time", "rt_tracer_read_buffer", "rt_tracer_copy_buffer_to_device",
+    "rt_tracer_kernel_time", "rt_tracer_read_buffer", "rt_tracer_copy_buffer_to_device", "rt_tracer_copy_buffer_to_device_async",
+    "rt_tracer_stream",
     "rt_tracer_device_pointer", "rt_tracer_buffer_bytes", "rt_tracer_info",
     "rt_tracer_last_error", "rt_last_error", "rt_device_count", "rt_version",
     "rt_dbg_hit_triangle", "rt_dbg_sincos", "rt_dbg_valu_peak", "rt_dbg_uniform", "rt_dbg_get_ray",
@@ -59,15 +60,43 @@ def library_path():
     return _LIB_PATH
 
 
+def _share_hip_runtime_with_torch():
+    """One process must not hold two HIP runtimes: PyTorch wheels bundle their own
+    libamdhip64.so (SONAME libamdhip64.so.7, the same as /opt/rocm's), and whichever copy
+    initialises second finds no device.  The multi-GPU driver (dist.py) needs torch.distributed
+    (RCCL) next to this library, so when a PyTorch install is present its libamdhip64 is mapped
+    first -- WITHOUT importing torch -- and librt_mi355x.so's NEEDED libamdhip64.so.7 binds to
+    that same object; a later `import torch` reuses it too.  RT_MI355X_HIP_RUNTIME=system
+    keeps /opt/rocm's runtime (then do not use torch.cuda in the same process)."""
+    if os.environ.get("RT_MI355X_HIP_RUNTIME", "") == "system":
+        return None
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return None
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            return cand
+    except (ImportError, OSError, ValueError):
+        pass
+    return None
+
+
+HIP_RUNTIME = None      # path of the HIP runtime shared with PyTorch, or None for /opt/rocm's
+
+
 def load_library():
     """dlopen librt_mi355x.so and declare the ABI.  Raises if the extension is missing."""
-    global _lib
+    global _lib, HIP_RUNTIME
     with _lib_lock:
         if _lib is not None:
             return _lib
         if not os.path.exists(_LIB_PATH):
             raise RtError("HIP extension not built: %s is missing (run `python -m raytracertest_amd.build` "
                           "or __graft_entry__.build()); there is no CPU fallback" % _LIB_PATH)
+        HIP_RUNTIME = _share_hip_runtime_with_torch()
         L = C.CDLL(_LIB_PATH)
         vp, u32p, f32p = C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_float)
         L.rt_tracer_create.argtypes = [u32p, f32p, f32p, C.c_float, C.c_float, C.c_float, C.POINTER(vp)]
@@ -103,6 +132,9 @@ def load_library():
         L.rt_tracer_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
         L.rt_tracer_read_buffer.argtypes = [vp, C.c_int, vp, C.c_size_t]
         L.rt_tracer_copy_buffer_to_device.argtypes = [vp, C.c_int, vp, C.c_size_t]
+        L.rt_tracer_copy_buffer_to_device_async.argtypes = [vp, C.c_int, vp, C.c_size_t]
+        L.rt_tracer_stream.argtypes = [vp]
+        L.rt_tracer_stream.restype = vp
         L.rt_tracer_device_pointer.argtypes = [vp, C.c_int]
         L.rt_tracer_device_pointer.restype = vp
         L.rt_tracer_buffer_bytes.argtypes = [vp, C.c_int]
@@ -271,6 +303,14 @@ class RayTracer:
 
     def CopyToDevice(self, which, dst_ptr, nbytes):
         self._check(self._lib.rt_tracer_copy_buffer_to_device(self._h, which, dst_ptr, nbytes))
+
+    def CopyToDeviceAsync(self, which, dst_ptr, nbytes):
+        """Enqueue the copy on the tracer's stream, no host sync (order other streams with Stream())."""
+        self._check(self._lib.rt_tracer_copy_buffer_to_device_async(self._h, which, dst_ptr, nbytes))
+
+    def Stream(self):
+        """The tracer's hipStream_t as an integer (torch.cuda.ExternalStream(ptr) wraps it)."""
+        return int(self._lib.rt_tracer_stream(self._h) or 0)
 
     def Info(self):
         out = np.zeros(8, np.uint32)

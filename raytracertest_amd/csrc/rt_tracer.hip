@@ -752,6 +752,16 @@ int rt_tracer_copy_buffer_to_device(rt_tracer* t, int which, void* dst_device, s
   });
 }
 
+int rt_tracer_copy_buffer_to_device_async(rt_tracer* t, int which, void* dst_device, size_t bytes) {
+  if (!t || !dst_device || buffer_ptr(t, which) == nullptr || bytes > buffer_bytes(t, which)) return RT_ERR_INVALID;
+  return guarded(t, [&] {
+    t->use_device();
+    HIP_CHECK(hipMemcpyAsync(dst_device, buffer_ptr(t, which), bytes, hipMemcpyDeviceToDevice, t->stream));
+  });
+}
+
+void* rt_tracer_stream(rt_tracer* t) { return t ? static_cast<void*>(t->stream) : nullptr; }
+
 int rt_tracer_info(rt_tracer* t, uint32_t out[8]) {
   if (!t || !out) return RT_ERR_INVALID;
   out[0] = t->last_k; out[1] = t->last_chunk; out[2] = t->last_lds;

@@ -10,6 +10,10 @@ RayTracerImpl.cu:287-305).  On the fully connected xGMI mesh every peer has its 
 to the root, so the G-1 tile transfers run in parallel; a ring all-reduce would be the
 wrong primitive (nothing is reduced).
 
+The gather of frame i runs on torch's stream while the tracer's own HIP stream already
+traces frame i+1 (two tile buffers, ordered with events through
+torch.cuda.ExternalStream): the host never blocks inside the loop.
+
 PyTorch is plumbing here (process group, device tensors for the gather); the compute is
 the C-ABI library.
 """
@@ -23,28 +27,34 @@ def band_rows(height, world, rank):
     return begin, end - begin
 
 
-def gather_tiles(tile, world, rank, group=None):
+def gather_tiles(tile, world, rank, group=None, all_rows=None, out=None):
     """Gather equal-or-ragged row tiles (torch tensors, (rows_i, W)) to rank 0.
 
     Returns the stacked (sum rows_i, W) tensor on rank 0, None elsewhere.  Ragged bands
-    are padded to the tallest band for the collective and cropped afterwards."""
+    are padded to the tallest band for the collective and cropped afterwards.
+    all_rows: the band heights of all ranks if already known (skips the size exchange);
+    out: preallocated list of `world` receive tensors on rank 0 (skips the allocation)."""
     import torch
     import torch.distributed as dist
     if world == 1:
         return tile
-    rows = torch.tensor([tile.shape[0]], dtype=torch.int64, device=tile.device)
-    all_rows = [torch.zeros_like(rows) for _ in range(world)]
-    dist.all_gather(all_rows, rows, group=group)
-    all_rows = [int(r.item()) for r in all_rows]
+    if all_rows is None:
+        rows = torch.tensor([tile.shape[0]], dtype=torch.int64, device=tile.device)
+        sizes = [torch.zeros_like(rows) for _ in range(world)]
+        dist.all_gather(sizes, rows, group=group)
+        all_rows = [int(r.item()) for r in sizes]
     tallest = max(all_rows)
     if tile.shape[0] != tallest:
         pad = torch.zeros((tallest - tile.shape[0],) + tuple(tile.shape[1:]), dtype=tile.dtype, device=tile.device)
         tile = torch.cat([tile, pad], dim=0)
     tile = tile.contiguous()
-    out = [torch.empty_like(tile) for _ in range(world)] if rank == 0 else None
-    dist.gather(tile, out, dst=0, group=group)
+    if rank == 0 and out is None:
+        out = [torch.empty_like(tile) for _ in range(world)]
+    dist.gather(tile, out if rank == 0 else None, dst=0, group=group)
     if rank != 0:
         return None
+    if len(set(all_rows)) == 1:
+        return torch.cat(out, dim=0) if out[0].shape[0] == all_rows[0] else torch.cat([t[:all_rows[0]] for t in out], dim=0)
     return torch.cat([t[:r] for t, r in zip(out, all_rows)], dim=0)
 
 
@@ -54,7 +64,8 @@ def update_due(i, update_interval, have_callback=True):
 
 
 def progressive_trace(launch, tile, world, rank, iterations, samples, update_interval,
-                      on_update=None, on_finished=None, stop_requested=None, all_reduce_max=None):
+                      on_update=None, on_finished=None, stop_requested=None, all_reduce_max=None,
+                      have_update_callback=None):
     """RayTracerImpl::TraceFunct (RayTracerImpl.cu:236-315) for a frame sharded in row bands.
 
     Every rank runs the same iteration loop on its own band; at an update iteration and at
@@ -68,22 +79,27 @@ def progressive_trace(launch, tile, world, rank, iterations, samples, update_int
       launch(samples, clear_first, emit_image)  -> enqueue one launch on this rank's band
       tile()                                    -> this rank's finished (rows, W) BGRA8 tensor
       all_reduce_max(flag: int) -> int          -> max of `flag` over ranks (identity if world == 1)
+      have_update_callback                      -> must agree on all ranks (default: on_update given)
     """
     if all_reduce_max is None:
         def all_reduce_max(v):
             return v
+    updates_on = (on_update is not None) if have_update_callback is None else bool(have_update_callback)
+
+    def stop_agreed():
+        want = 1 if (rank == 0 and stop_requested is not None and stop_requested()) else 0
+        return bool(all_reduce_max(want))
+
     for i in range(iterations):
-        want_stop = 1 if (rank == 0 and stop_requested is not None and stop_requested()) else 0
-        if all_reduce_max(want_stop):
+        if stop_agreed():
             return False
-        upd = update_due(i, update_interval, on_update is not None)
+        upd = update_due(i, update_interval, updates_on)
         launch(samples, i == 0, upd or i + 1 == iterations)
         if upd:
             frame = gather_tiles(tile(), world, rank)
             if rank == 0 and on_update is not None:
                 on_update(frame)
-    want_stop = 1 if (rank == 0 and stop_requested is not None and stop_requested()) else 0
-    if all_reduce_max(want_stop):
+    if stop_agreed():
         return False
     if iterations == 0:
         return True
@@ -104,7 +120,6 @@ class RowBandJob:
         import raytracertest_amd as R
         self.cfg, self.world, self.rank = cfg, world, rank
         self.torch = None
-        self.image_t = None
         if world > 1:
             import torch
             import torch.distributed as dist
@@ -115,9 +130,11 @@ class RowBandJob:
         W, H = cfg["width"], cfg["height"]
         if weak:
             full_h, row0, rows = H * world, H * rank, H
+            self.all_rows = [H] * world
         else:
             full_h = H
             row0, rows = band_rows(H, world, rank)
+            self.all_rows = [band_rows(H, world, r)[1] for r in range(world)]
         self.full_height, self.row0, self.rows = full_h, row0, rows
         self.tracer = R.RayTracer((W, rows), (0.0, 0.0, 0.0), cfg["angles"], cfg["fov"], cfg["focal"],
                                   cfg["aperture"], seed=cfg["seed"], device=local_rank, math_mode=math_mode,
@@ -127,43 +144,81 @@ class RowBandJob:
             assert self.tracer.UploadScene(tris)
         if spheres.shape[0]:
             self.tracer.UploadSpheres(spheres)
-        if world > 1:
-            self.image_t = self.torch.empty((rows, W), dtype=self.torch.int32, device="cuda")
         self.frame = None
+        self.step_index = 0
+        if world > 1:
+            t = self.torch
+            tallest = max(self.all_rows)
+            # two tile buffers: frame i is gathered from one while frame i+1 is copied into the other
+            self.tiles = [t.zeros((tallest, W), dtype=t.int32, device="cuda") for _ in range(2)]
+            self.recv = [[t.empty((tallest, W), dtype=t.int32, device="cuda") for _ in range(world)] for _ in range(2)] \
+                if rank == 0 else [None, None]
+            self.trace_stream = t.cuda.ExternalStream(self.tracer.Stream(), device=t.device("cuda", local_rank))   # the tracer's own HIP stream
+            self.copied = [t.cuda.Event() for _ in range(2)]      # tile i copied (recorded on the tracer's stream)
+            self.gathered = [t.cuda.Event() for _ in range(2)]    # tile i consumed by the gather (torch's stream)
 
+    # ---- throughput path (bench.py) -------------------------------------------------------
     def step(self):
-        """One Trace pass on device-resident buffers (+ tile gather when sharded)."""
+        """One Trace pass on device-resident buffers (+ tile gather when sharded).  Nothing here
+        blocks the host: the copy is ordered behind the trace on the tracer's stream, the gather
+        behind the copy through an event, and buffer reuse behind the previous gather."""
         cfg = self.cfg
+        if self.world == 1:
+            self.tracer.TraceEnqueue(cfg["iterations"], cfg["samples"])
+            return
+        from .api import BUF_IMAGE
+        b = self.step_index & 1
+        self.step_index += 1
+        self.trace_stream.wait_event(self.gathered[b])            # buffer b is free again (no-op the first time)
         self.tracer.TraceEnqueue(cfg["iterations"], cfg["samples"])
-        if self.world > 1:
-            from .api import BUF_IMAGE
-            # hipMemcpyAsync on the tracer's stream + stream sync, then RCCL on torch's stream
-            self.tracer.CopyToDevice(BUF_IMAGE, self.image_t.data_ptr(), self.image_t.numel() * 4)
-            self.frame = gather_tiles(self.image_t, self.world, self.rank)
+        self.tracer.CopyToDeviceAsync(BUF_IMAGE, self.tiles[b].data_ptr(), self.rows * cfg["width"] * 4)
+        self.copied[b].record(self.trace_stream)
+        cur = self.torch.cuda.current_stream()
+        cur.wait_event(self.copied[b])
+        self.dist.gather(self.tiles[b], self.recv[b] if self.rank == 0 else None, dst=0)
+        self.gathered[b].record(cur)
+        self.last_buffer = b
 
+    def finish(self):
+        self.tracer.Sync()
+        if self.world > 1:
+            self.torch.cuda.synchronize()
+
+    def gathered_image(self):
+        """(full rows, W) uint32 BGRA8 on rank 0 after finish() (None elsewhere)."""
+        if self.world == 1:
+            return self.tracer.Image()
+        if self.rank != 0 or self.step_index == 0:
+            return None
+        t = self.torch
+        parts = [buf[:r] for buf, r in zip(self.recv[self.last_buffer], self.all_rows)]
+        return t.cat(parts, dim=0).cpu().numpy().view(np.uint32)
+
+    # ---- progressive path (callbacks on rank 0) ---------------------------------------------
     def _tile(self):
         """Finished BGRA8 band as a torch tensor ready for the collective (host-syncs the tracer)."""
         from .api import BUF_IMAGE
         if self.world == 1:
             import torch
             return torch.from_numpy(self.tracer.Image().view(np.int32))
-        self.tracer.CopyToDevice(BUF_IMAGE, self.image_t.data_ptr(), self.image_t.numel() * 4)
-        return self.image_t
+        tile = self.tiles[0][:self.rows]
+        self.tracer.CopyToDevice(BUF_IMAGE, tile.data_ptr(), self.rows * self.cfg["width"] * 4)
+        return tile
 
     def trace_progressive(self, iterations, samples, update_interval, on_update=None, on_finished=None,
-                          stop_requested=None, have_update_callback=None):
+                          stop_requested=None):
         """Multi-GPU Trace with the reference's callback cadence; callbacks run on rank 0 with
-        the gathered (full rows, W) frame.  `have_update_callback` must be the same on every
-        rank (defaults to: rank 0 passes on_update)."""
-        flag = on_update is not None if have_update_callback is None else have_update_callback
-        if self.world > 1 and have_update_callback is None:
-            flag = bool(self._all_reduce_max(1 if on_update is not None else 0))
+        the gathered (full rows, W) frame.  Whether updates happen at all is rank 0's choice
+        (it passes on_update), agreed on by all ranks."""
+        updates_on = bool(self._all_reduce_max(1 if (self.rank == 0 and on_update is not None) else 0))
+
         def launch(spp, clear_first, emit):
             self.tracer.Launch(spp, clear_first, emit)
+
         ok = progressive_trace(launch, self._tile, self.world, self.rank, iterations, samples, update_interval,
-                               on_update=on_update if self.rank == 0 else (None if not flag else (lambda f: None)),
-                               on_finished=on_finished, stop_requested=stop_requested,
-                               all_reduce_max=self._all_reduce_max)
+                               on_update=on_update if self.rank == 0 else None, on_finished=on_finished,
+                               stop_requested=stop_requested, all_reduce_max=self._all_reduce_max,
+                               have_update_callback=updates_on)
         self.tracer.Sync()
         return ok
 
@@ -174,11 +229,7 @@ class RowBandJob:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return int(t.item())
 
-    def finish(self):
-        self.tracer.Sync()
-        if self.world > 1:
-            self.torch.cuda.synchronize()
-
+    # ---- bench plumbing ----------------------------------------------------------------------
     def barrier(self):
         if self.world > 1:
             self.dist.barrier()
@@ -190,14 +241,6 @@ class RowBandJob:
         t = self.torch.tensor([seconds], dtype=self.torch.float64, device="cuda")
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
-
-    def gathered_image(self):
-        """(full rows, W) uint32 BGRA8 on rank 0 after the last step (None elsewhere)."""
-        if self.world == 1:
-            return self.tracer.Image()
-        if self.frame is None:
-            return None
-        return self.frame.cpu().numpy().view(np.uint32)
 
     def close(self):
         self.tracer.close()

@@ -389,3 +389,30 @@ def test_launch_building_block_and_progressive_driver(rt, orc):
                                on_finished=lambda f: finished.append(None), stop_requested=lambda: stop["n"] >= 2)
     assert not ok and len(finished) == 1 and int(job.tracer.SampleCounts().max()) == 5    # launches 0..4, then agreed stop
     job.close()
+
+
+def test_stream_interop_for_the_overlapped_gather(rt):
+    """The pieces dist.RowBandJob.step() relies on for N > 1, exercised on one GPU: the tracer's
+    HIP stream wrapped as a torch ExternalStream, an async copy ordered behind the trace, an
+    event making torch's stream wait for it."""
+    import torch
+    import raytracertest_amd as R
+    from raytracertest_amd import scenes
+    from raytracertest_amd.api import BUF_IMAGE
+    g = R.RayTracer((96, 54), (0, 0, 0), (0, 0), 70.0, 3.0, 0.05, seed=1)
+    g.UploadScene(scenes.cornell32())
+    assert g.Stream() != 0
+    ext = torch.cuda.ExternalStream(g.Stream(), device=torch.device("cuda", 0))
+    tile = torch.zeros((54, 96), dtype=torch.int32, device="cuda")
+    ev = torch.cuda.Event()
+    for _ in range(3):
+        g.TraceEnqueue(1, 4)
+        g.CopyToDeviceAsync(BUF_IMAGE, tile.data_ptr(), tile.numel() * 4)
+        ev.record(ext)
+        torch.cuda.current_stream().wait_event(ev)
+        doubled = tile * 2                       # consumer on torch's stream
+    torch.cuda.synchronize()
+    g.Sync()
+    img = g.Image()
+    assert np.array_equal(tile.cpu().numpy().view(np.uint32), img)
+    assert np.array_equal(doubled.cpu().numpy(), (img.view(np.int32) * 2))
