@@ -164,7 +164,7 @@ def main():
                          "note": "contractual bound; the path is fp32-VALU-bound by construction "
                                  "(SURVEY.md 0.5, BASELINE.md 2): see valu"},
         }
-        if not args.no_valu:
+        if not args.no_valu and world == 1:      # (rank 0 must not fall behind its peers before the group is torn down)
             # instrumented launch of the reference's own algorithm (every ray scans the whole list,
             # reference-order tests) on a scratch tracer: exit points per test
             g = R.RayTracer((cfg["width"], cfg["height"]), (0, 0, 0), cfg["angles"], cfg["fov"], cfg["focal"],
