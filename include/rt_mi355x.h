@@ -180,6 +180,9 @@ int rt_dbg_hit_triangle(int device, uint32_t math_mode, uint32_t n, const float*
                         const float* tris, int eps_mode, int32_t* hit, float* tuv, float* normal,
                         float* point);
 int rt_dbg_sincos(int device, uint32_t n, const float* x, float* s, float* c);
+/* 256-thread blocks of the default trace kernel (K = samples_in_flight) the occupancy API admits
+ * per CU with lds_bytes of dynamic LDS (measurement aid). */
+int rt_dbg_trace_occupancy(int device, int samples_in_flight, uint32_t lds_bytes);
 /* fp32 VALU calibration on this device: attainable lane-FMA/s (8 fma chains per lane,
  * 8 waves per SIMD, every CU) and the shader clock held meanwhile.  Measurement aid only. */
 int rt_dbg_valu_peak(int device, double* lane_fma_per_s, double* clock_ghz);

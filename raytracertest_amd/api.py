@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "rt_tracer_stream",
     "rt_tracer_device_pointer", "rt_tracer_buffer_bytes", "rt_tracer_info",
     "rt_tracer_last_error", "rt_last_error", "rt_device_count", "rt_version",
-    "rt_dbg_hit_triangle", "rt_dbg_sincos", "rt_dbg_valu_peak", "rt_dbg_uniform", "rt_dbg_get_ray",
+    "rt_dbg_hit_triangle", "rt_dbg_sincos", "rt_dbg_valu_peak", "rt_dbg_trace_occupancy", "rt_dbg_uniform", "rt_dbg_get_ray",
     "rt_dbg_rng_init_host",
 ]
 
@@ -150,6 +150,7 @@ def load_library():
         L.rt_dbg_sincos.argtypes = [C.c_int, C.c_uint32, f32p, f32p, f32p]
         L.rt_dbg_uniform.argtypes = [C.c_int, C.c_uint32, C.c_uint32, u32p, f32p]
         L.rt_dbg_valu_peak.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.rt_dbg_trace_occupancy.argtypes = [C.c_int, C.c_int, C.c_uint32]
         L.rt_dbg_get_ray.argtypes = [vp, C.c_uint32, u32p, u32p, f32p]
         L.rt_dbg_rng_init_host.argtypes = [C.c_uint64, C.c_uint64, u32p]
         L.rt_dbg_rng_init_host.restype = None

@@ -209,13 +209,20 @@ uint32_t trace_lds_bytes(const TraceParams& p, bool bin) {
   return staged * 36u;
 }
 
+template <bool FMA, bool FILTER, bool STATS, bool BIN, bool ONEPASS>
+static void launch_trace_o(const TraceParams& p, int K, dim3 grid, size_t lds, hipStream_t st) {
+  switch (K) {
+    case 1: hipLaunchKernelGGL((trace_kernel<FMA, 1, FILTER, STATS, BIN, ONEPASS>), grid, dim3(256), lds, st, p); break;
+    case 2: hipLaunchKernelGGL((trace_kernel<FMA, 2, FILTER, STATS, BIN, ONEPASS>), grid, dim3(256), lds, st, p); break;
+    default: hipLaunchKernelGGL((trace_kernel<FMA, 4, FILTER, STATS, BIN, ONEPASS>), grid, dim3(256), lds, st, p); break;
+  }
+}
+
 template <bool FMA, bool FILTER, bool STATS, bool BIN>
 static void launch_trace_k(const TraceParams& p, int K, dim3 grid, size_t lds, hipStream_t st) {
-  switch (K) {
-    case 1: hipLaunchKernelGGL((trace_kernel<FMA, 1, FILTER, STATS, BIN>), grid, dim3(256), lds, st, p); break;
-    case 2: hipLaunchKernelGGL((trace_kernel<FMA, 2, FILTER, STATS, BIN>), grid, dim3(256), lds, st, p); break;
-    default: hipLaunchKernelGGL((trace_kernel<FMA, 4, FILTER, STATS, BIN>), grid, dim3(256), lds, st, p); break;
-  }
+  // one classification pass suffices when the whole scene fits the per-wave candidate list
+  if (BIN && p.n_tris <= p.bin_list) launch_trace_o<FMA, FILTER, STATS, BIN, BIN>(p, K, grid, lds, st);
+  else launch_trace_o<FMA, FILTER, STATS, BIN, false>(p, K, grid, lds, st);
 }
 
 template <bool FMA, bool FILTER, bool STATS>
@@ -242,6 +249,16 @@ hipError_t launch_trace(const TraceParams& p, bool fma, bool filter, bool bin, i
     else launch_trace_f<false, false>(p, filter, bin, K, grid, lds, st);
   }
   return hipGetLastError();
+}
+
+// blocks of the default (fma, filtered, binned) trace kernel the occupancy API admits per CU
+int trace_occupancy(int K, size_t lds) {
+  int n = 0;
+  hipError_t e;
+  if (K == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<true, 1, true, false, true, true>, 256, lds);
+  else if (K == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<true, 2, true, false, true, true>, 256, lds);
+  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<true, 4, true, false, true, false>, 256, lds);
+  return e == hipSuccess ? n : -1;
 }
 
 hipError_t launch_convert(const float4* render, const uint32_t* counts, uint32_t* image, uint32_t npix,

@@ -47,6 +47,7 @@ uint32_t trace_lds_bytes(const TraceParams& p, bool bin);
 // bin: per-tile triangle classification + per-wave LDS candidate lists (rt_trace.hpp);
 // !bin: every ray scans the whole list, staged into LDS in chunks of p.chunk.
 hipError_t launch_trace(const TraceParams& p, bool fma, bool filter, bool bin, int K, hipStream_t st);
+int trace_occupancy(int K, size_t lds);
 hipError_t launch_convert(const float4* render, const uint32_t* counts, uint32_t* image, uint32_t npix,
                           hipStream_t st);
 

@@ -821,6 +821,12 @@ int rt_dbg_valu_peak(int device, double* lane_fma_per_s, double* clock_ghz) {
   });
 }
 
+int rt_dbg_trace_occupancy(int device, int samples_in_flight, uint32_t lds_bytes) {
+  if (require_device(device) != RT_OK) return -1;
+  if (hipSetDevice(device) != hipSuccess) return -1;
+  return rtk::trace_occupancy(samples_in_flight, lds_bytes);
+}
+
 int rt_dbg_sincos(int device, uint32_t n, const float* x, float* s, float* c) {
   int rc = require_device(device);
   if (rc != RT_OK) return rc;
