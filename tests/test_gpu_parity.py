@@ -427,3 +427,14 @@ def test_randomised_campaign_default_kernel_equals_plain_full_scan(rt):
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_binning.py"), "250", "31337"],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "250 configurations, 0 mismatches" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_randomised_campaign_hip_equals_oracle(rt):
+    """tests/stress_oracle.py: random scenes, spheres, cameras, row bands, seeds, both arithmetic
+    modes and both hit rules -- HIP vs oracle, bit for bit (21 500 configurations run once for
+    round 1: 0 mismatches; 300 here)."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "stress_oracle.py"), "300", "424242"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "300 configurations, 0 mismatches" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
