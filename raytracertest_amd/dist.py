@@ -124,9 +124,19 @@ class RowBandJob:
             import torch
             import torch.distributed as dist
             self.torch, self.dist = torch, dist
+            # Rehearsal knobs (a 1-GPU box cannot host two RCCL ranks): RT_DIST_BACKEND=gloo stages the
+            # tiles through host memory for the collective, RT_DIST_SHARE_GPU=1 lets all ranks use
+            # the devices round-robin.  The product path is nccl (RCCL), one GPU per rank.
+            import os
+            self.backend = os.environ.get("RT_DIST_BACKEND", "nccl")
+            if os.environ.get("RT_DIST_SHARE_GPU", "") == "1":
+                local_rank = local_rank % max(torch.cuda.device_count(), 1)
             torch.cuda.set_device(local_rank)
             if not dist.is_initialized():
-                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+                if self.backend == "nccl":
+                    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+                else:
+                    dist.init_process_group(backend=self.backend)
         W, H = cfg["width"], cfg["height"]
         if weak:
             full_h, row0, rows = H * world, H * rank, H
@@ -175,7 +185,15 @@ class RowBandJob:
         self.copied[b].record(self.trace_stream)
         cur = self.torch.cuda.current_stream()
         cur.wait_event(self.copied[b])
-        self.dist.gather(self.tiles[b], self.recv[b] if self.rank == 0 else None, dst=0)
+        if self.backend == "nccl":
+            self.dist.gather(self.tiles[b], self.recv[b] if self.rank == 0 else None, dst=0)
+        else:                                                    # rehearsal: collective on host copies
+            host = self.tiles[b].cpu()
+            parts = [self.torch.empty_like(host) for _ in range(self.world)] if self.rank == 0 else None
+            self.dist.gather(host, parts, dst=0)
+            if self.rank == 0:
+                for dst, src in zip(self.recv[b], parts):
+                    dst.copy_(src)
         self.gathered[b].record(cur)
         self.last_buffer = b
 
@@ -203,7 +221,7 @@ class RowBandJob:
             return torch.from_numpy(self.tracer.Image().view(np.int32))
         tile = self.tiles[0][:self.rows]
         self.tracer.CopyToDevice(BUF_IMAGE, tile.data_ptr(), self.rows * self.cfg["width"] * 4)
-        return tile
+        return tile if self.backend == "nccl" else tile.cpu()
 
     def trace_progressive(self, iterations, samples, update_interval, on_update=None, on_finished=None,
                           stop_requested=None):
@@ -225,7 +243,7 @@ class RowBandJob:
     def _all_reduce_max(self, v):
         if self.world == 1:
             return v
-        t = self.torch.tensor([int(v)], dtype=self.torch.int32, device="cuda")
+        t = self.torch.tensor([int(v)], dtype=self.torch.int32, device="cuda" if self.backend == "nccl" else "cpu")
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return int(t.item())
 
@@ -238,7 +256,7 @@ class RowBandJob:
     def max_over_ranks(self, seconds):
         if self.world == 1:
             return seconds
-        t = self.torch.tensor([seconds], dtype=self.torch.float64, device="cuda")
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device="cuda" if self.backend == "nccl" else "cpu")
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 

@@ -438,3 +438,23 @@ def test_randomised_campaign_hip_equals_oracle(rt):
     out = subprocess.run([sys.executable, os.path.join(root, "tests", "stress_oracle.py"), "300", "424242"],
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "300 configurations, 0 mismatches" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_two_rank_rehearsal_of_the_multi_gpu_driver(rt):
+    """The whole N > 1 path of dist.RowBandJob / bench.py with two processes on this one GPU
+    (gloo stands in for RCCL, which refuses two ranks per device): tests/dist_rehearsal.py."""
+    import subprocess, sys, os, socket
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, RT_DIST_BACKEND="gloo", RT_DIST_SHARE_GPU="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(root, "tests", "dist_rehearsal.py")], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "dist_rehearsal ok: world=2" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--steps", "5", "--warmup", "2"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    import json
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0 and "cpu_baseline" not in line
