@@ -234,30 +234,37 @@ __device__ __forceinline__ void test_triangle(const float4 A0, const float4 A1, 
 // ------------------------------------------------------------------------------------
 // BIN: conservative classification of one triangle against the whole ray family of a tile.
 //
-// Ray family of a wave: every lens origin o in the box oc +- orad and every direction d in
-// the box dc +- drad (bounds over all 64 pixels of the tile and the whole lens disk, widened
-// for rounding; built by tile_family()).  For any such ray let det, U, V be the values the
-// REFERENCE arithmetic computes (either math mode).  With midpoint-radius interval
-// arithmetic (P = abscross(|d|max, |e2|), T = |tv|max, Q = abscross(T, |e1|)):
-//   |det - detc| <= dot(|e1|, pvr) + c*dot(|e1|, P)                    =: det_rad
-//   |U   - Uc  | <= dot(|tvc|, pvr) + dot(tvr, |pvc| + pvr) + c*dot(T, P)  =: U_rad
-//   |V   - Vc  | <= dot(|dc|, qvr) + dot(drad, |qvc| + qvr) + c*dot(|d|max, Q) =: V_rad
-// where pvr = abscross(drad, |e2|), qvr = abscross(tvr, |e1|) are the interval radii and
-// c = 4e-6 (~67 ulp) dominates every rounding error of the reference's evaluation AND of
-// this one (each is <= ~10 ulp of the same magnitude sums).  The triangle can be dropped
-// for the whole tile when one of the following holds for the interval ends, because then
-// the per-ray rules proven above test_triangle() make every ray of the family a certain miss:
-//   det_hi < eps                                   every ray culled (:42)
-//   U_hi < -1e-6 * det_hi     (det_hi > 0)         every unculled ray has u < 0
-//   U_lo > 1.0002 * det_hi                         every unculled ray has u > 1
-//   V_hi < -1e-6 * det_hi                          every remaining ray has v < 0
-//   U_lo + V_lo > 1.0002 * det_hi                  every remaining ray has u + v > 1
-// Any NaN makes the comparisons false -> the triangle is kept and the exact tests decide.
-// tests/test_gpu_parity.py::test_binning_* compare BIN against the full scan bit for bit.
+// Ray family of a wave: every lens origin o in the box oc +- orad and, for every in-image
+// pixel of the tile, its focal point F (a box fc +- frad over the 64 pixels); a ray is the line
+// through o with direction w/|w|, w = F - o (ThinLensCamera.cuh:44-50).  Writing the three
+// quantities of HitTriangle with the UNNORMALISED direction,
+//     det' = w.(e2 x e1)      U' = (o - v0).(w x e2)      V' = w.((o - v0) x e1)
+// (det, U, V of Kernels.cuh:39-57 are these divided by |w|), and o = oc + do, F = fc + dF,
+// the polynomials expand EXACTLY -- the dependency between origin and direction is resolved
+// analytically, which is what makes the bounds tight for in-focus geometry -- to
+//     det' = wc.N + (dF - do).N                                   N = e2 x e1, wc = fc - oc
+//     U'   = tvc.(wc x e2) + do.(G x e2) + dF.(e2 x tvc) + do.(dF x e2)     tvc = oc - v0
+//     V'   = wc.(tvc x e1) + do.(e1 x G) + dF.(tvc x e1) + dF.(do x e1)     G = fc - v0
+// so with |do_i| <= orad_i, |dF_i| <= frad_i the radii are plain absolute-value sums.  For every
+// ray of the family the values the REFERENCE arithmetic computes (either math mode) satisfy
+//     |det_c |w| - det'| , |U_c |w| - U'| , |V_c |w| - V'|  <=  c * (magnitude sums)
+// with c = 4e-6 (~67 ulp) covering every rounding of the reference's evaluation (normalisation
+// of w included, ~20 ulp) and of this one.  With *_hi / *_lo the interval ends and
+// lmin <= |w| <= lmax, the triangle can be dropped for the whole tile when
+//     det_hi < eps * lmin                          every ray culled (:42)
+//     U_hi < -1e-6 * det_hi      (det_hi > 0)      every unculled ray has u < 0
+//     U_lo > 1.0002 * det_hi                       every unculled ray has u > 1
+//     V_hi < -1e-6 * det_hi                        every remaining ray has v < 0
+//     U_lo + V_lo > 1.0002 * det_hi                every remaining ray has u + v > 1
+// because the per-ray rules proven above test_triangle() are homogeneous in |w| > 0.  Any NaN
+// makes the comparisons false -> the triangle is kept and the exact tests decide.
+// tests/test_gpu_parity.py::test_binning_* and tools/stress_binning.py compare BIN against the
+// full scan bit for bit.
 // ------------------------------------------------------------------------------------
 struct TileFamily {
   float oc[3], orad[3];   // lens origin box (wave-uniform)
-  float dc[3], drad[3];   // direction box  (wave-uniform)
+  float fc[3], frad[3];   // focal point box over the tile's pixels (wave-uniform)
+  float lmin, lmax;       // bounds of |F - o| over the family
   bool usable;            // false: bounds not finite -> keep every triangle
 };
 
@@ -275,9 +282,9 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// Bounds of (origin, direction) over every sample of every in-image pixel of the wave.
-// o = pos + (dx*aperture, dy*aperture, 0) with |dx|,|dy| <= 1.0000003 (sr <= 1, build-owned
-// sincos within 2 ulp of [-1,1]); d = normalize(focal_pixel - o) up to ~5 ulp.
+// Bounds over every sample of every in-image pixel of the wave.  o = pos + (dx*aperture,
+// dy*aperture, 0) with |dx|,|dy| <= 1.0000003 (sr <= 1, build-owned sincos within 2 ulp of
+// [-1,1]); `focal` is this lane's focal point exactly as the rays use it.
 __device__ __forceinline__ TileFamily tile_family(const TraceParams& p, V3 focal, bool inside) {
   TileFamily f;
   const float A = __builtin_fabsf(p.aperture) * 1.000002f;
@@ -285,79 +292,71 @@ __device__ __forceinline__ TileFamily tile_family(const TraceParams& p, V3 focal
   f.orad[0] = A + 1e-6f * __builtin_fabsf(f.oc[0]);
   f.orad[1] = A + 1e-6f * __builtin_fabsf(f.oc[1]);
   f.orad[2] = 1e-6f * __builtin_fabsf(f.oc[2]);
-  const float fc[3] = {focal.x, focal.y, focal.z};
-  float lo[3], hi[3], lmin2 = 0.0f, lmax2 = 0.0f;
+  const float fl[3] = {focal.x, focal.y, focal.z};
+  bool finite = true;
+  float lmin2 = 0.0f, lmax2 = 0.0f;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    const float wc = fc[i] - f.oc[i];
-    const float wr = f.orad[i] + 2e-7f * (__builtin_fabsf(fc[i]) + __builtin_fabsf(f.oc[i]));
-    lo[i] = wc - wr;
-    hi[i] = wc + wr;
+    finite = finite && (__builtin_fabsf(fl[i]) <= FLT_MAX);         // false for NaN/inf
+    const float lo = uniform(wave_min(inside ? fl[i] : FLT_MAX));   // out-of-image lanes do not constrain
+    const float hi = uniform(wave_max(inside ? fl[i] : -FLT_MAX));
+    f.fc[i] = 0.5f * (lo + hi);
+    f.frad[i] = 0.5f * (hi - lo) * 1.00001f + 1e-6f * (__builtin_fabsf(lo) + __builtin_fabsf(hi));
+    const float wc = f.fc[i] - f.oc[i];
+    const float wr = f.frad[i] + f.orad[i] + 2e-7f * (__builtin_fabsf(f.fc[i]) + __builtin_fabsf(f.oc[i]));
     const float amin = fmaxf(__builtin_fabsf(wc) - wr, 0.0f), amax = __builtin_fabsf(wc) + wr;
     lmin2 = __builtin_fmaf(amin, amin, lmin2);
     lmax2 = __builtin_fmaf(amax, amax, lmax2);
   }
-  const float rlo = (1.0f / __builtin_sqrtf(lmax2)) * 0.999998f;    // smallest 1/|w|
-  const float rhi = (1.0f / __builtin_sqrtf(lmin2)) * 1.000002f;    // largest  1/|w| (inf when the box touches 0)
-  bool finite = true;
-  float dlo[3], dhi[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    float a = (lo[i] >= 0.0f) ? lo[i] * rlo : lo[i] * rhi;
-    float b = (hi[i] >= 0.0f) ? hi[i] * rhi : hi[i] * rlo;
-    finite = finite && (__builtin_fabsf(a) <= 2.0f) && (__builtin_fabsf(b) <= 2.0f);   // false for NaN/inf
-    if (!inside) { a = FLT_MAX; b = -FLT_MAX; }                     // out-of-image lanes do not constrain
-    dlo[i] = wave_min(a);
-    dhi[i] = wave_max(b);
-  }
+  f.lmin = __builtin_sqrtf(lmin2) * 0.999998f;
+  f.lmax = __builtin_sqrtf(lmax2) * 1.000002f;
   const bool bad = __builtin_amdgcn_ballot_w64(inside && !finite) != 0ull;
   const bool any_inside = __builtin_amdgcn_ballot_w64(inside) != 0ull;
-  f.usable = !bad && any_inside && (A <= FLT_MAX);
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    // the reductions left the same value in every lane: tell the compiler (SGPRs, not VGPRs)
-    const float lo_u = uniform(dlo[i]), hi_u = uniform(dhi[i]);
-    f.dc[i] = 0.5f * (lo_u + hi_u);
-    f.drad[i] = 0.5f * (hi_u - lo_u) * 1.00001f + 2e-6f;
-  }
+  f.usable = !bad && any_inside && (A <= FLT_MAX) && (f.lmax <= FLT_MAX);
   return f;
 }
 
 // true = every ray of the family certainly misses this triangle (see the block comment)
 __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0, V3 e1, V3 e2) {
   const float c = 4e-6f;
-  const float E1[3] = {__builtin_fabsf(e1.x), __builtin_fabsf(e1.y), __builtin_fabsf(e1.z)};
-  const float E2[3] = {__builtin_fabsf(e2.x), __builtin_fabsf(e2.y), __builtin_fabsf(e2.z)};
   const float e1v[3] = {e1.x, e1.y, e1.z}, e2v[3] = {e2.x, e2.y, e2.z}, v0v[3] = {v0.x, v0.y, v0.z};
-  float D[3], tvc[3], tvr[3], T[3];
+  float E1[3], E2[3], wc[3], W[3], dw[3], tvc[3], T[3], G[3], a[3], r[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    D[i] = __builtin_fabsf(f.dc[i]) + f.drad[i];
+    E1[i] = __builtin_fabsf(e1v[i]);
+    E2[i] = __builtin_fabsf(e2v[i]);
+    a[i] = f.orad[i] + 2e-7f * (__builtin_fabsf(f.oc[i]) + __builtin_fabsf(v0v[i]));   // |do| incl. rounding of o - v0
+    r[i] = f.frad[i];
+    wc[i] = f.fc[i] - f.oc[i];
+    dw[i] = r[i] + a[i] + 2e-7f * (__builtin_fabsf(f.fc[i]) + __builtin_fabsf(f.oc[i]));   // |dF - do|
+    W[i] = __builtin_fabsf(wc[i]) + dw[i];                          // >= |w_i| for every ray
     tvc[i] = f.oc[i] - v0v[i];
-    tvr[i] = f.orad[i] + 2e-7f * (__builtin_fabsf(f.oc[i]) + __builtin_fabsf(v0v[i]));
-    T[i] = __builtin_fabsf(tvc[i]) + tvr[i];
-  }
-  // cross(a, b)_i = a_j*b_k - b_j*a_k with (i,j,k) cyclic
-  float pvc[3], pvr[3], P[3], qvc[3], qvr[3], Q[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int j = (i + 1) % 3, k = (i + 2) % 3;
-    pvc[i] = f.dc[j] * e2v[k] - e2v[j] * f.dc[k];                   // cross(d, e2)
-    pvr[i] = f.drad[j] * E2[k] + E2[j] * f.drad[k];
-    P[i] = D[j] * E2[k] + E2[j] * D[k];
-    qvc[i] = tvc[j] * e1v[k] - e1v[j] * tvc[k];                     // cross(tv, e1)
-    qvr[i] = tvr[j] * E1[k] + E1[j] * tvr[k];
-    Q[i] = T[j] * E1[k] + E1[j] * T[k];
+    T[i] = __builtin_fabsf(tvc[i]) + a[i];                          // >= |(o - v0)_i|
+    G[i] = f.fc[i] - v0v[i];
   }
   float detc = 0.0f, det_rad = 0.0f, Uc = 0.0f, U_rad = 0.0f, Vc = 0.0f, V_rad = 0.0f;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    detc += e1v[i] * pvc[i];
-    det_rad += E1[i] * pvr[i] + c * (E1[i] * P[i]);
-    Uc += tvc[i] * pvc[i];
-    U_rad += __builtin_fabsf(tvc[i]) * pvr[i] + tvr[i] * (__builtin_fabsf(pvc[i]) + pvr[i]) + c * (T[i] * P[i]);
-    Vc += f.dc[i] * qvc[i];
-    V_rad += __builtin_fabsf(f.dc[i]) * qvr[i] + f.drad[i] * (__builtin_fabsf(qvc[i]) + qvr[i]) + c * (D[i] * Q[i]);
+    const int j = (i + 1) % 3, k = (i + 2) % 3;                     // cross(x, y)_i = x_j*y_k - y_j*x_k
+    const float N_i = e2v[j] * e1v[k] - e1v[j] * e2v[k];            // (e2 x e1)_i
+    const float Nabs = E2[j] * E1[k] + E1[j] * E2[k];
+    const float wxe2 = wc[j] * e2v[k] - e2v[j] * wc[k];             // (wc x e2)_i
+    const float Wxe2 = W[j] * E2[k] + E2[j] * W[k];                 // >= |(w x e2)_i|
+    const float Gxe2 = G[j] * e2v[k] - e2v[j] * G[k];               // (G x e2)_i
+    const float e2xt = e2v[j] * tvc[k] - tvc[j] * e2v[k];           // (e2 x tvc)_i
+    const float rxe2 = r[j] * E2[k] + E2[j] * r[k];                 // >= |(dF x e2)_i|
+    const float txe1 = tvc[j] * e1v[k] - e1v[j] * tvc[k];           // (tvc x e1)_i
+    const float Txe1 = T[j] * E1[k] + E1[j] * T[k];                 // >= |((o - v0) x e1)_i|
+    const float e1xG = e1v[j] * G[k] - G[j] * e1v[k];               // (e1 x G)_i
+    const float axe1 = a[j] * E1[k] + E1[j] * a[k];                 // >= |(do x e1)_i|
+    const float Gabs = (__builtin_fabsf(G[j]) * E2[k] + E2[j] * __builtin_fabsf(G[k])) +
+                       (E1[j] * __builtin_fabsf(G[k]) + __builtin_fabsf(G[j]) * E1[k]);   // rounding of G x e2, e1 x G
+    detc += wc[i] * N_i;
+    det_rad += dw[i] * __builtin_fabsf(N_i) + c * (W[i] * Nabs);
+    Uc += tvc[i] * wxe2;
+    U_rad += a[i] * (__builtin_fabsf(Gxe2) + rxe2) + r[i] * __builtin_fabsf(e2xt) + c * (T[i] * Wxe2 + a[i] * Gabs);
+    Vc += wc[i] * txe1;
+    V_rad += a[i] * __builtin_fabsf(e1xG) + r[i] * (__builtin_fabsf(txe1) + axe1) + c * (W[i] * Txe1 + a[i] * Gabs);
   }
   det_rad = det_rad * 1.00001f;
   U_rad = U_rad * 1.00001f;
@@ -365,7 +364,7 @@ __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0,
   const float det_hi = detc + det_rad;
   const float U_lo = Uc - U_rad, U_hi = Uc + U_rad, V_lo = Vc - V_rad, V_hi = Vc + V_rad;
   const float neg = det_hi * -1e-6f, big = det_hi * 1.0002f;
-  const bool all_culled = det_hi < RT_EPS;
+  const bool all_culled = det_hi < RT_EPS * f.lmin;
   const bool pos = det_hi > 0.0f;
   const bool out = pos && ((U_hi < neg) || (U_lo > big) || (V_hi < neg) || ((U_lo + V_lo) > big));
   return all_culled || out;
