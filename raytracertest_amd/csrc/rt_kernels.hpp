@@ -26,6 +26,7 @@ struct TraceParams {
   uint32_t  n_spheres;
   uint32_t  chunk;          // triangles staged into LDS at a time (full-scan path)
   uint32_t  bin_list;       // candidate records per wave in LDS (binned path), multiple of 64
+  uint32_t  block_list;     // block-level pre-cull list (indices) in LDS; 0 = every wave scans the scene
   unsigned long long* stats; // null in the product path; 16 counters for the instrumented launch
   uint32_t* image;     // rows*W BGRA8, written when flags & TRACE_EMIT_IMAGE (mImageBuffer)
   uint32_t  flags;     // TRACE_*

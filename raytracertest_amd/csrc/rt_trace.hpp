@@ -282,24 +282,42 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// Bounds over every sample of every in-image pixel of the wave.  o = pos + (dx*aperture,
-// dy*aperture, 0) with |dx|,|dy| <= 1.0000003 (sr <= 1, build-owned sincos within 2 ulp of
-// [-1,1]); `focal` is this lane's focal point exactly as the rays use it.
-__device__ __forceinline__ TileFamily tile_family(const TraceParams& p, V3 focal, bool inside) {
+// Wave-uniform bounds of the focal points of the wave's in-image pixels (`focal` is this
+// lane's focal point exactly as its rays use it).
+struct FocalBounds {
+  float lo[3], hi[3];
+  bool ok;                // every in-image lane had a finite focal point
+  bool any;               // the wave has at least one in-image lane
+};
+
+__device__ __forceinline__ FocalBounds focal_bounds(V3 focal, bool inside) {
+  FocalBounds b;
+  const float fl[3] = {focal.x, focal.y, focal.z};
+  bool finite = true;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    finite = finite && (__builtin_fabsf(fl[i]) <= FLT_MAX);         // false for NaN/inf
+    b.lo[i] = uniform(wave_min(inside ? fl[i] : FLT_MAX));          // out-of-image lanes do not constrain
+    b.hi[i] = uniform(wave_max(inside ? fl[i] : -FLT_MAX));
+  }
+  b.ok = __builtin_amdgcn_ballot_w64(inside && !finite) == 0ull;
+  b.any = __builtin_amdgcn_ballot_w64(inside) != 0ull;
+  return b;
+}
+
+// Ray family over every sample of every pixel inside the focal bounds.  o = pos + (dx*aperture,
+// dy*aperture, 0) with |dx|,|dy| <= 1.0000003 (sr <= 1, build-owned sincos within 2 ulp of [-1,1]).
+__device__ __forceinline__ TileFamily make_family(const TraceParams& p, const FocalBounds& b) {
   TileFamily f;
   const float A = __builtin_fabsf(p.aperture) * 1.000002f;
   f.oc[0] = p.cam[9]; f.oc[1] = p.cam[10]; f.oc[2] = p.cam[11];
   f.orad[0] = A + 1e-6f * __builtin_fabsf(f.oc[0]);
   f.orad[1] = A + 1e-6f * __builtin_fabsf(f.oc[1]);
   f.orad[2] = 1e-6f * __builtin_fabsf(f.oc[2]);
-  const float fl[3] = {focal.x, focal.y, focal.z};
-  bool finite = true;
   float lmin2 = 0.0f, lmax2 = 0.0f;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    finite = finite && (__builtin_fabsf(fl[i]) <= FLT_MAX);         // false for NaN/inf
-    const float lo = uniform(wave_min(inside ? fl[i] : FLT_MAX));   // out-of-image lanes do not constrain
-    const float hi = uniform(wave_max(inside ? fl[i] : -FLT_MAX));
+    const float lo = b.lo[i], hi = b.hi[i];
     f.fc[i] = 0.5f * (lo + hi);
     f.frad[i] = 0.5f * (hi - lo) * 1.00001f + 1e-6f * (__builtin_fabsf(lo) + __builtin_fabsf(hi));
     const float wc = f.fc[i] - f.oc[i];
@@ -310,9 +328,7 @@ __device__ __forceinline__ TileFamily tile_family(const TraceParams& p, V3 focal
   }
   f.lmin = __builtin_sqrtf(lmin2) * 0.999998f;
   f.lmax = __builtin_sqrtf(lmax2) * 1.000002f;
-  const bool bad = __builtin_amdgcn_ballot_w64(inside && !finite) != 0ull;
-  const bool any_inside = __builtin_amdgcn_ballot_w64(inside) != 0ull;
-  f.usable = !bad && any_inside && (A <= FLT_MAX) && (f.lmax <= FLT_MAX);
+  f.usable = b.ok && b.any && (A <= FLT_MAX) && (f.lmax <= FLT_MAX);
   return f;
 }
 
@@ -372,7 +388,8 @@ __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0,
 
 // ------------------------------------------------------------------------------------
 // The trace kernel.  grid = (ceil(W/32), ceil(rows/8)), block = 256 threads.
-// Dynamic LDS: BIN ? 4 waves * bin_list * 40 bytes : min(n_tris, chunk) * 36 bytes.
+// Dynamic LDS: BIN ? 4 waves * bin_list * 40 bytes (+ block_list * 4 + 160 bytes for the block-level
+// pre-cull) : min(n_tris, chunk) * 36 bytes.
 // ------------------------------------------------------------------------------------
 template <bool FMA, int K, bool FILTER, bool STATS, bool BIN, bool ONEPASS>
 __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) void trace_kernel(const TraceParams p) {
@@ -437,15 +454,82 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   TileFamily fam;
   bool list_complete = false;       // the list in LDS covers the whole scene (classification done once)
   uint32_t list_count = 0;
-  if constexpr (BIN) fam = tile_family(p, focal, inside);
+  // Block-level pre-cull (scenes larger than the per-wave list): the 256 threads classify every
+  // triangle ONCE against the union of the block's four tile families and keep the survivors'
+  // indices, in ascending order, in LDS; each wave then only refines that short list against its
+  // own tile.  4x fewer classifications and triangle-list reads than every wave scanning the scene.
+  const uint32_t Lb = p.block_list;
+  uint32_t* const bI = reinterpret_cast<uint32_t*>(s_mem + 4u * 2u * L) + 8u * L;           // Lb indices
+  uint32_t* const bcnt = bI + Lb;                                                           // 2 x 4 wave counts
+  float* const bbox = reinterpret_cast<float*>(bcnt + 8);                                   // 4 waves x (lo[3], hi[3], ok, any)
+  uint32_t src_count = n;           // triangles the wave-level classification walks over
+  bool src_is_block_list = false;
+  if constexpr (BIN) {
+    const FocalBounds wb = focal_bounds(focal, inside);
+    fam = make_family(p, wb);
+    if constexpr (!ONEPASS) {
+      if (Lb != 0u) {
+        if (lane == 0u) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) { bbox[wave * 8u + i] = wb.lo[i]; bbox[wave * 8u + 3 + i] = wb.hi[i]; }
+          bbox[wave * 8u + 6] = wb.ok ? 1.0f : 0.0f;
+          bbox[wave * 8u + 7] = wb.any ? 1.0f : 0.0f;
+        }
+        __syncthreads();
+        FocalBounds bb;
+        bb.ok = true; bb.any = false;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { bb.lo[i] = FLT_MAX; bb.hi[i] = -FLT_MAX; }
+        for (uint32_t w = 0; w < 4u; ++w) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            bb.lo[i] = fminf(bb.lo[i], bbox[w * 8u + i]);
+            bb.hi[i] = fmaxf(bb.hi[i], bbox[w * 8u + 3 + i]);
+          }
+          bb.ok = bb.ok && (bbox[w * 8u + 6] != 0.0f);
+          bb.any = bb.any || (bbox[w * 8u + 7] != 0.0f);
+        }
+        const TileFamily bfam = make_family(p, bb);
+        uint32_t total = 0;
+        bool overflow = false;
+        uint32_t step = 0;
+        for (uint32_t base = 0; base < n; base += 256u, ++step) {
+          const uint32_t tri = base + threadIdx.x;
+          const bool valid = tri < n;
+          const uint32_t ti = valid ? tri : (n - 1u);
+          const float4 A0 = p.tri_a[2u * ti], A1 = p.tri_a[2u * ti + 1u];
+          const float bz = p.tri_b[ti];
+          bool keep = valid;
+          if (bfam.usable)
+            keep = valid && !tile_misses_triangle(bfam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z});
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+          uint32_t* const slot = bcnt + (step & 1u) * 4u;          // double-buffered: one barrier per step
+          if (lane == 0u) slot[wave] = static_cast<uint32_t>(__builtin_popcountll(m));
+          __syncthreads();
+          const uint32_t c0 = slot[0], c1 = slot[1], c2 = slot[2], c3 = slot[3];
+          const uint32_t before = (wave > 0u ? c0 : 0u) + (wave > 1u ? c1 : 0u) + (wave > 2u ? c2 : 0u);
+          const uint32_t step_total = c0 + c1 + c2 + c3;
+          if (total + step_total > Lb) { overflow = true; break; }   // block-uniform
+          const uint32_t pos = total + before + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
+                                                                      __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+          if (keep) bI[pos] = tri;                                 // ascending order across waves and steps
+          total += step_total;
+        }
+        __syncthreads();
+        if (!overflow) { src_count = total; src_is_block_list = true; }
+      }
+    }
+  }
 
   // classify triangles [from, n) until the list is full; returns the first unclassified index
   auto classify = [&](uint32_t from) -> uint32_t {
     uint32_t count = 0, base = from;
-    while (base < n && count + 64u <= L) {
-      const uint32_t tri = base + lane;
-      const bool valid = tri < n;
-      const uint32_t ti = valid ? tri : (n - 1u);
+    while (base < src_count && count + 64u <= L) {
+      const uint32_t e = base + lane;
+      const bool valid = e < src_count;
+      const uint32_t ei = valid ? e : (src_count - 1u);
+      const uint32_t tri = src_is_block_list ? bI[ei] : ei;
+      const uint32_t ti = tri;
       const float4 A0 = p.tri_a[2u * ti], A1 = p.tri_a[2u * ti + 1u];
       const float bz = p.tri_b[ti];
       bool keep = valid;
@@ -467,7 +551,7 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
     __builtin_amdgcn_wave_barrier();
     list_count = count;
     if constexpr (STATS) { st_bin[0] += count; st_bin[1] += 1; }
-    return base < n ? base : n;
+    return base < src_count ? base : src_count;
   };
 
   // ONEPASS: the scene has no more triangles than the list holds (host-checked), so one
@@ -496,10 +580,10 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
     } else if constexpr (BIN) {
       uint32_t base = 0;
       do {
-        uint32_t next = n;
+        uint32_t next = src_count;
         if (!list_complete) {
           next = classify(base);
-          if (base == 0u && next >= n) list_complete = true;
+          if (base == 0u && next >= src_count) list_complete = true;
         }
         for (uint32_t j = 0; j < list_count; ++j) {                // ascending triangle order
           const float4 A0 = cA[2u * j], A1 = cA[2u * j + 1u];
@@ -508,7 +592,7 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
         }
         base = next;
         if (!list_complete) __builtin_amdgcn_wave_barrier();       // list is rewritten by the next round
-      } while (!list_complete && base < n);
+      } while (!list_complete && base < src_count);
     } else {
       for (uint32_t c0 = 0; c0 < n; c0 += p.chunk) {
         const uint32_t cn = (n - c0 < p.chunk) ? n - c0 : p.chunk;

@@ -230,6 +230,11 @@ struct rt_tracer {
     uint32_t want = bin_list_req ? bin_list_req : ((n_tris + 63u) / 64u) * 64u;
     want = ((want + 63u) / 64u) * 64u;
     p.bin_list = want < 64u ? 64u : want > (bin_list_req ? 960u : 256u) ? (bin_list_req ? 960u : 256u) : want;
+    // scenes that do not fit the per-wave list: 192 records per wave + a 1024-entry block-level
+    // pre-cull list keep the block at 34.9 KiB of LDS (4 blocks per CU)
+    const char* nb = getenv("RT_MI355X_NO_BLOCK_LIST");
+    p.block_list = (n_tris > p.bin_list && !(nb && nb[0] == '1')) ? 1024u : 0u;
+    if (p.block_list != 0u && !bin_list_req) p.bin_list = 192u;
     return p;
   }
 

@@ -324,7 +324,8 @@ def _stress_scene(kind, n, seed):
     return scenes._tri_rows(t)
 
 
-@pytest.mark.parametrize("kind,n", [("around_origin", 400), ("big_overlapping", 700), ("grazing", 500), ("scales", 500)])
+@pytest.mark.parametrize("kind,n", [("around_origin", 400), ("big_overlapping", 700), ("big_overlapping", 3000),
+                                    ("grazing", 500), ("scales", 500), ("scales", 5000)])
 @pytest.mark.parametrize("mode", [0, 1])
 def test_binning_equals_full_scan_stress(rt, kind, n, mode):
     _bin_pair(72, 40, _stress_scene(kind, n, 11), 1, 6, mode=mode, aperture=0.08, focal=3.0)
