@@ -259,7 +259,9 @@ struct rt_tracer {
   // RunTraceKernel, RayTracerImpl.cu:204-234, without the blocking wait.  `flags` are the
   // TRACE_* fusions: the first launch after the clear treats the accumulators as zero (no
   // memset, no accumulator read), a launch whose result is handed out also writes BGRA8.
-  void enqueue_trace_launch(uint32_t samples, uint32_t flags, bool sync_after) {
+  // sync_after: 0 = none, 1 = wait for this launch (the reference's behaviour, :228),
+  // N > 1 = keep at most N launches in flight (wait for the launch N-1 back).
+  void enqueue_trace_launch(uint32_t samples, uint32_t flags, int sync_after) {
     const int K = pick_k(samples);
     rtk::TraceParams p = params(samples);
     p.flags = flags | (nearest_hit ? rtk::TRACE_NEAREST_HIT : 0u);
@@ -271,18 +273,32 @@ struct rt_tracer {
     HIP_CHECK(hipEventRecord(e.a, stream));
     HIP_CHECK(rtk::launch_trace(p, fma, filter, bin, K, stream));
     HIP_CHECK(hipEventRecord(e.b, stream));
-    { std::lock_guard<std::mutex> lk(time_mu); pending.push_back(e); }
-    if (sync_after) { HIP_CHECK(hipEventSynchronize(e.b)); }              // :228
+    hipEvent_t wait_for = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(time_mu);
+      pending.push_back(e);
+      if (sync_after == 1) wait_for = e.b;
+      else if (sync_after > 1 && pending.size() >= static_cast<size_t>(sync_after))
+        wait_for = pending[pending.size() - static_cast<size_t>(sync_after)].b;
+    }
+    if (wait_for) {
+      HIP_CHECK(hipEventSynchronize(wait_for));                           // :228
+      if (sync_after > 1) drain_events(static_cast<size_t>(sync_after - 1));   // everything older has finished: recycle
+    }
   }
 
-  void drain_events() {
+  // account and recycle the event pairs of finished launches, keeping the newest `keep_last`
+  void drain_events(size_t keep_last = 0) {
     std::lock_guard<std::mutex> lk(time_mu);
-    for (EventPair& e : pending) {
+    if (pending.size() <= keep_last) return;
+    const size_t n_done = pending.size() - keep_last;
+    for (size_t i = 0; i < n_done; ++i) {
+      EventPair& e = pending[i];
       float ms = 0.0f;
       if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { kernel_ms += ms; kernel_launches += e.launches; }
       free_events.push_back(e);
     }
-    pending.clear();
+    pending.erase(pending.begin(), pending.begin() + static_cast<std::ptrdiff_t>(n_done));
   }
 
   void clear_accumulators() {                                            // :242-243
@@ -300,6 +316,8 @@ struct rt_tracer {
     HIP_CHECK(hipStreamSynchronize(stream));                             // :259,:287
   }
 
+  static constexpr int kWindow = 4;
+
   // RayTracerImpl::TraceFunct, RayTracerImpl.cu:236-315 (runs on the render thread)
   void trace_funct(uint32_t iterationCount, uint32_t samplesPerIteration, uint32_t updateInterval) {
     try {
@@ -311,7 +329,10 @@ struct rt_tracer {
         const bool update = cb != nullptr && i > 0 && updateInterval > 0 && i % updateInterval == 0;   // :256
         const uint32_t flags = (cleared ? 0u : rtk::TRACE_ZERO_ACC) |
                                ((update || i + 1 == iterationCount) ? rtk::TRACE_EMIT_IMAGE : 0u);
-        enqueue_trace_launch(samplesPerIteration, flags, true);          // :249
+        // The reference blocks on every launch (:228), which makes a stop take effect after one
+        // kernel.  Here up to `kWindow` launches are in flight: the host never starves the GPU on
+        // short launches, and a stop still takes effect within kWindow kernels.
+        enqueue_trace_launch(samplesPerIteration, flags, update ? 1 : kWindow);          // :249
         cleared = true;
         if (update) {
           fetch_image();                                                 // :259-270 (conversion fused)
@@ -685,7 +706,7 @@ int rt_tracer_trace_enqueue(rt_tracer* t, uint32_t iterationCount, uint32_t samp
       t->enqueue_trace_launch(samplesPerIteration,
                               (i == 0 ? rtk::TRACE_ZERO_ACC : 0u) |
                                   (i + 1 == iterationCount ? rtk::TRACE_EMIT_IMAGE : 0u),
-                              false);
+                              0);
   });
 }
 
@@ -696,7 +717,7 @@ int rt_tracer_launch(rt_tracer* t, uint32_t samples, int clear_first, int emit_i
     t->cancel_and_join();
     t->use_device();
     t->enqueue_trace_launch(samples, (clear_first ? rtk::TRACE_ZERO_ACC : 0u) | (emit_image ? rtk::TRACE_EMIT_IMAGE : 0u),
-                            false);
+                            0);
   });
 }
 

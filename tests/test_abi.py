@@ -59,3 +59,13 @@ def test_product_does_not_touch_the_oracle():
                     if re.search(r"oracle", txt, re.I):
                         bad.append(os.path.join(dirpath, f))
     assert bad == []
+
+
+def test_header_is_plain_c99(tmp_path):
+    """The boundary must be bindable from C: include/rt_mi355x.h compiles as pedantic C99."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include "rt_mi355x.h"\nint main(void) { rt_options o; o.struct_size = sizeof o; '
+                   'return rt_device_count() < 0 ? (int)o.struct_size : 0; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"),
+                    "-c", str(src), "-o", str(tmp_path / "abi.o")], check=True)
