@@ -80,7 +80,19 @@ def cpu_baseline(cfg, tris, spheres, rows, threads):
         o.launch(cfg["samples"])
     dt = time.perf_counter() - t0
     rays = cfg["width"] * rows * cfg["samples"] * launches
+    # the same oracle on ONE thread, on a 64-row slice (~2 core-seconds), for a per-core figure
+    one_rows = min(rows, 64)
+    o1 = orc.OracleTracer(cfg["width"], H, cfg["angles"], cfg["fov"], cfg["focal"], cfg["aperture"], seed=cfg["seed"],
+                          row0=(H - one_rows) // 2, rows=one_rows, contract=orc.FMA, nthreads=1)
+    if tris.shape[0]:
+        o1.upload_scene(tris)
+    if spheres.shape[0]:
+        o1.upload_spheres(spheres)
+    t1 = time.perf_counter()
+    o1.launch(cfg["samples"])
+    one = cfg["width"] * one_rows * cfg["samples"] / (time.perf_counter() - t1) / 1e6
     return {"value": round(rays / dt / 1e6, 3), "unit": "Mray/s", "cores": threads, "kind": "port",
+            "value_1core": round(one, 3),
             "sample": "%d centred rows of the %dx%d frame (rows %d..%d), %d launches x %d spp = %d rays, %.1f s wall "
                       "(%.0f core-seconds); oracle/oracle.c, gcc -O2 -ffp-contract=off, scalar, row-threaded"
                       % (rows, cfg["width"], H, row0, row0 + rows - 1, launches, cfg["samples"], rays, dt, dt * threads)}
