@@ -29,6 +29,7 @@ struct TraceParams {
   uint32_t  block_list;     // block-level pre-cull list (indices) in LDS; 0 = every wave scans the scene
   unsigned long long* stats; // null in the product path; 16 counters for the instrumented launch
   uint32_t* image;     // rows*W BGRA8, written when flags & TRACE_EMIT_IMAGE (mImageBuffer)
+  uint32_t* tile_lists; // per wave tile: count + bin_list triangle indices (TRACE_LISTS_*), or null
   uint32_t  flags;     // TRACE_*
 };
 
@@ -39,6 +40,10 @@ constexpr uint32_t TRACE_ZERO_ACC = 1u;
 constexpr uint32_t TRACE_EMIT_IMAGE = 2u;
 // Hit selection: keep the nearest t > 0 instead of the reference's farthest t (build-defined extension).
 constexpr uint32_t TRACE_NEAREST_HIT = 4u;
+// ONEPASS kernels: store each tile's candidate list to TraceParams::tile_lists / load it from there
+// instead of classifying (valid while camera, scene and frame are unchanged; the host decides).
+constexpr uint32_t TRACE_LISTS_STORE = 8u;
+constexpr uint32_t TRACE_LISTS_LOAD = 16u;
 
 hipError_t launch_rng_init(uint32_t* rng, uint32_t npix, uint32_t p0, const uint32_t seeded[6],
                            const uint32_t* jump, hipStream_t st);

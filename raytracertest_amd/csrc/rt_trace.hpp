@@ -557,7 +557,36 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   // ONEPASS: the scene has no more triangles than the list holds (host-checked), so one
   // classification before any ray exists is enough; keeping it out of the sample loop saves
   // ~17 VGPRs (K = 2: 98 -> 96 with 5 waves/SIMD; measured C3 202 -> 192 us).
-  if constexpr (BIN && ONEPASS) { (void)classify(0u); list_complete = true; }
+  // Later launches of the same Trace (same camera, scene and frame: host-checked) reuse the
+  // tile's candidate list that the first launch stored in HBM instead of re-classifying: the
+  // list depends on the tile's ray family only, not on the samples.
+  if constexpr (BIN && ONEPASS) {
+    const size_t slot = (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 4u + wave;
+    uint32_t* const saved = p.tile_lists + slot * (1u + L);
+    if (p.flags & TRACE_LISTS_LOAD) {
+      const uint32_t count = saved[0];                              // wave-uniform
+      for (uint32_t base = 0; base < count; base += 64u) {
+        const uint32_t e = base + lane;
+        if (e < count) {
+          const uint32_t tri = saved[1u + e];
+          cA[2u * e] = p.tri_a[2u * tri];
+          cA[2u * e + 1u] = p.tri_a[2u * tri + 1u];
+          cB[e] = p.tri_b[tri];
+          cI[e] = static_cast<int>(tri);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      list_count = count;
+    } else {
+      (void)classify(0u);
+      if (p.flags & TRACE_LISTS_STORE) {
+        if (lane == 0u) saved[0] = list_count;
+        for (uint32_t e = lane; e < list_count; e += 64u) saved[1u + e] = static_cast<uint32_t>(cI[e]);
+      }
+    }
+    list_complete = true;
+  }
   for (uint32_t s0 = 0; s0 < p.samples; s0 += K) {                 // :134, K samples per pass
     V3 o[K], d[K];
     float best_t[K];

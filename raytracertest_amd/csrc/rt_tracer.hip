@@ -266,6 +266,7 @@ struct rt_tracer {
     rtk::TraceParams p = params(samples);
     p.flags = flags | (nearest_hit ? rtk::TRACE_NEAREST_HIT : 0u);
     p.image = d_image;
+    attach_tile_lists(p, (flags & rtk::TRACE_ZERO_ACC) != 0u);
     last_k = K; last_chunk = p.chunk;
     last_lds = rtk::trace_lds_bytes(p, bin);
     EventPair e = take_events();
@@ -314,6 +315,49 @@ struct rt_tracer {
     HIP_CHECK(hipMemcpyAsync(h_image, d_image, static_cast<size_t>(npix()) * sizeof(uint32_t),
                              hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));                             // :259,:287
+  }
+
+  // Candidate lists of a Trace's first launch are kept for its later launches (ONEPASS scenes):
+  // same camera snapshot, scene, frame and list length => same lists (they do not depend on the
+  // samples).  A launch that clears the accumulators starts a new Trace and always re-classifies,
+  // so single-launch passes (bench.py's step) never read a cached list.
+  struct ListKey {
+    float cam[12], half_height, aspect, focal, aperture;
+    uint32_t W, H, row0, rows, bin_list, n_tris, scene_generation;
+    bool fma;
+  };
+  uint32_t* d_tile_lists = nullptr;
+  size_t tile_lists_words = 0;
+  ListKey list_key{};
+  bool list_key_valid = false;
+  uint32_t scene_generation = 0;
+
+  void attach_tile_lists(rtk::TraceParams& p, bool first_launch_of_trace) {
+    p.tile_lists = nullptr;
+    if (!bin || p.n_tris == 0u || p.n_tris > p.bin_list || getenv("RT_MI355X_NO_LIST_REUSE")) return;
+    const size_t tiles = static_cast<size_t>((W + 31u) / 32u) * ((rows + 7u) / 8u) * 4u;
+    const size_t words = tiles * (1u + p.bin_list);
+    if (words > tile_lists_words) {
+      if (d_tile_lists) (void)hipFree(d_tile_lists);
+      d_tile_lists = nullptr; tile_lists_words = 0; list_key_valid = false;
+      HIP_CHECK(hipMalloc(&d_tile_lists, words * sizeof(uint32_t)));
+      tile_lists_words = words;
+    }
+    ListKey k;
+    memset(&k, 0, sizeof k);                       // padding too: the key is compared bytewise
+    memcpy(k.cam, p.cam, sizeof k.cam);
+    k.half_height = p.half_height; k.aspect = p.aspect; k.focal = p.focal; k.aperture = p.aperture;
+    k.W = p.W; k.H = p.H; k.row0 = p.row0; k.rows = p.rows; k.bin_list = p.bin_list; k.n_tris = p.n_tris;
+    k.scene_generation = scene_generation; k.fma = fma;
+    p.tile_lists = d_tile_lists;
+    const bool same = list_key_valid && memcmp(&k, &list_key, sizeof k) == 0;
+    if (!first_launch_of_trace && same) {
+      p.flags |= rtk::TRACE_LISTS_LOAD;
+    } else {
+      p.flags |= rtk::TRACE_LISTS_STORE;
+      list_key = k;
+      list_key_valid = true;
+    }
   }
 
   static constexpr int kWindow = 4;
@@ -530,6 +574,7 @@ void rt_tracer_destroy(rt_tracer* t) {                                   // RayT
   if (t->stream) (void)hipStreamSynchronize(t->stream);
   t->drain_events();
   for (EventPair& e : t->free_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  if (t->d_tile_lists) (void)hipFree(t->d_tile_lists);
   if (t->d_tri) (void)hipFree(t->d_tri);
   if (t->d_tri_b) (void)hipFree(t->d_tri_b);
   if (t->d_tri_color) (void)hipFree(t->d_tri_color);
@@ -623,6 +668,7 @@ static int upload_scene_impl(rt_tracer* t, const rt_float4* hostData, size_t cou
                                          t->d_tri_color, t->stream));
     HIP_CHECK(hipStreamSynchronize(t->stream));
     t->n_tris = n;
+    t->scene_generation++;
   });
 }
 
