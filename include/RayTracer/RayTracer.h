@@ -70,6 +70,11 @@ public:
   void UploadSpheres(const std::vector<float4>& spheres) {
     if (mImpl) rt_tracer_upload_spheres(mImpl, reinterpret_cast<const rt_float4*>(spheres.data()), spheres.size());
   }
+  // (v0, e0 = v1-v0, e1 = v2-v0) rows with packed vertex normals in .w (Documentation/gpu.meshes.txt:16-34;
+  // pack with rt::pack, Common/NormalPacking.h); smooth shading needs RT_FLAG_SMOOTH_NORMALS in rt_options
+  void UploadSceneEdges(const std::vector<float4>& hostData) {
+    if (mImpl) rt_tracer_upload_scene_edges(mImpl, reinterpret_cast<const rt_float4*>(hostData.data()), hostData.size());
+  }
   bool ReadRenderBuffer(std::vector<float>& rgba) {
     if (!mImpl) return false;
     rgba.resize(rt_tracer_buffer_bytes(mImpl, RT_BUF_RENDER) / sizeof(float));

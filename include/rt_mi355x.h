@@ -45,6 +45,11 @@ extern "C" {
 #define RT_FLAG_NEAREST_HIT 4u  /* hit selection extension: keep the nearest hit with t > 0 instead of the
                                   reference's farthest hit incl. negative t (Kernels.cuh:73,84).  Not the default. */
 
+#define RT_FLAG_SMOOTH_NORMALS 8u /* shading extension for scenes uploaded with rt_tracer_upload_scene_edges: the
+                                  colour is |normalize(w*n0 + u*n1 + v*n2)|, the rows' packed vertex normals
+                                  interpolated at the hit (w = (1-u)-v), instead of |face normal| (Kernels.cuh:97-99).
+                                  No effect on scenes uploaded as absolute vertices.  Not the default. */
+
 #define RT_BUF_RENDER      0   /* rows*W*4 float  RGBA accumulators   (mRenderBuffer)      */
 #define RT_BUF_COUNTS      1   /* rows*W   uint32 sample counts       (mSampleCountBuffer) */
 #define RT_BUF_IMAGE       2   /* rows*W   uint32 BGRA8               (mImageBuffer)       */

@@ -238,6 +238,19 @@ void orc_camera_set(orc_camera* cam, float fov_deg, float focal, float aperture)
 /* =====================================================================================
  * Mode-dependent arithmetic, instantiated twice
  * ===================================================================================== */
+float orc_pack_normal(const float n[3]) {
+  return floorf(n[0] * 127.0f + 127.5f) / 256.0f + floorf(n[1] * 127.0f + 127.5f) / 65536.0f +
+         floorf(n[2] * 127.0f + 127.5f) / 16777216.0f;
+}
+
+void orc_unpack_normal(float packed, float n[3]) {
+  float shift = 1.0f;
+  for (int k = 0; k < 3; ++k, shift *= 256.0f) {
+    const float s = packed * shift;
+    n[k] = floorf((s - floorf(s)) * 256.0f) / 127.0f - 1.0f;
+  }
+}
+
 #define ORC_FN(n) n##_strict
 #define ORC_CONTRACT 0
 #include "oracle_core.inc"
@@ -295,6 +308,12 @@ void orc_camera_get_ray(const orc_camera* cam, uint32_t px, uint32_t py, uint32_
   if (contract) r = get_ray_fma(cam, pinhole_fma(cam, hh, px, py, W, H), rng);
   else r = get_ray_strict(cam, pinhole_strict(cam, hh, px, py, W, H), rng);
   st3(out, r.o); st3(out + 3, r.d);
+}
+
+void orc_normalize(const float v[3], int contract, float out[3]) {
+  const v3 a = {v[0], v[1], v[2]};
+  const v3 n = contract ? normalize_fma(a) : normalize_strict(a);
+  out[0] = n.x; out[1] = n.y; out[2] = n.z;
 }
 
 void orc_radiance(const orc_scene* sc, const float ray[6], int contract, float rgb[3]) {

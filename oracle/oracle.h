@@ -93,7 +93,19 @@ typedef struct orc_scene {
   uint32_t     n_spheres;
   int32_t      hit_mode;  /* 0: reference rule (farthest hit, negative t accepted, Kernels.cuh:73,84);
                              1: nearest hit with t > 0 (build-defined extension) */
+  int32_t      layout;    /* 0: absolute vertices (RayTracerImpl.cu:119-177);
+                             1: (v0, e0 = v1-v0, e1 = v2-v0) rows with a packed vertex normal in each .w
+                                (Documentation/gpu.meshes.txt:16-34; build-defined) */
+  int32_t      shade_mode; /* 0: |face normal| (Kernels.cuh:97-99);
+                              1: |interpolated vertex normal|, layout 1 only (build-defined) */
 } orc_scene;
+
+/* Corrected form of the reference's experimental packing (UnitTests/NormalPackingTest.cpp:10-23):
+ * byte_k = floor(n_k*127 + 127.5); packed = byte_0/2^8 + byte_1/2^16 + byte_2/2^24;
+ * unpack: n_k = floor(fract(packed * 256^k) * 256) / 127 - 1.  PARITY UNPINNED (the reference's
+ * own test of its version cannot pass). */
+float orc_pack_normal(const float n[3]);
+void  orc_unpack_normal(float packed, float n[3]);
 
 /* A frame is a row band [row0, row0+rows) of a W x H image.  Buffers hold the band only:
  * render rows*W*4 floats (RGBA, alpha never written, Kernels.cuh:141-144), counts rows*W,
@@ -107,6 +119,7 @@ typedef struct orc_frame {
 } orc_frame;
 
 void orc_radiance(const orc_scene* sc, const float ray[6], int contract, float rgb[3]);
+void orc_normalize(const float v[3], int contract, float out[3]);        /* glm::normalize */
 void orc_frame_rng_init(orc_frame* f, uint64_t seed, int nthreads);      /* Random.cu:10-52   */
 void orc_frame_clear(orc_frame* f);                                      /* RayTracerImpl.cu:242-243 */
 void orc_trace_launch(const orc_scene* sc, const orc_camera* cam, orc_frame* f,

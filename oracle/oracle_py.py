@@ -33,7 +33,8 @@ class Camera(C.Structure):
 
 class Scene(C.Structure):
     _fields_ = [("tris", C.POINTER(C.c_float)), ("n_tris", C.c_uint32),
-                ("spheres", C.POINTER(C.c_float)), ("n_spheres", C.c_uint32), ("hit_mode", C.c_int32)]
+                ("spheres", C.POINTER(C.c_float)), ("n_spheres", C.c_uint32), ("hit_mode", C.c_int32),
+                ("layout", C.c_int32), ("shade_mode", C.c_int32)]
 
 
 class Frame(C.Structure):
@@ -154,6 +155,35 @@ def hit_sphere(ray, sph, contract=FMA):
     return bool(hit), np.float32(t.value)
 
 
+def radiance(ray, tri_rows=None, spheres=None, contract=FMA, hit_mode=0, layout=0, shade_mode=0):
+    """rt::Radiance (Kernels.cuh:68-107) of one ray against a scene given as float4 rows."""
+    tris = np.ascontiguousarray(_f32(tri_rows if tri_rows is not None else np.zeros((0, 4))).reshape(-1, 12))
+    sph = np.ascontiguousarray(_f32(spheres if spheres is not None else np.zeros((0, 4))).reshape(-1, 4))
+    sc = Scene(_fp(tris), tris.shape[0], _fp(sph), sph.shape[0], hit_mode, layout, shade_mode)
+    out = np.zeros(3, np.float32)
+    lib().orc_radiance(C.byref(sc), _fp(_f32(ray)), contract, _fp(out))
+    return out
+
+
+def normalize(v, contract=FMA):
+    out = np.zeros(3, np.float32)
+    lib().orc_normalize.argtypes = [C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float)]
+    lib().orc_normalize(_fp(_f32(v)), contract, _fp(out))
+    return out
+
+
+def pack_normal(n):
+    lib().orc_pack_normal.restype = C.c_float
+    return np.float32(lib().orc_pack_normal(_fp(_f32(n))))
+
+
+def unpack_normal(packed):
+    out = np.zeros(3, np.float32)
+    lib().orc_unpack_normal.argtypes = [C.c_float, C.POINTER(C.c_float)]
+    lib().orc_unpack_normal(C.c_float(float(packed)), _fp(out))
+    return out
+
+
 def camera(angles=(0.0, 0.0), fov_deg=70.0, focal=10.0, aperture=4.0):
     cam = Camera()
     lib().orc_camera_init(C.byref(cam), _fp(_f32(angles)), fov_deg, focal, aperture)
@@ -172,11 +202,12 @@ class OracleTracer:
     :105-117 (camera), :119-177 (UploadScene)."""
 
     def __init__(self, width, height, angles=(0.0, 0.0), fov_deg=70.0, focal=10.0, aperture=4.0,
-                 seed=1, row0=0, rows=None, contract=FMA, nthreads=1, hit_mode=0):
+                 seed=1, row0=0, rows=None, contract=FMA, nthreads=1, hit_mode=0, smooth_normals=False):
         self.W, self.H = int(width), int(height)
         self.row0 = int(row0)
         self.rows = int(self.H - self.row0 if rows is None else rows)
         self.contract, self.nthreads, self.seed, self.hit_mode = contract, nthreads, seed, hit_mode
+        self.layout, self.shade_mode = 0, int(bool(smooth_normals))
         self.cam = camera(angles, fov_deg, focal, aperture)
         self.tris = np.zeros((0, 12), np.float32)
         self.spheres = np.zeros((0, 4), np.float32)
@@ -195,6 +226,14 @@ class OracleTracer:
         if a.shape[0] < 3 or a.shape[0] % 3 != 0:      # RayTracerImpl.cu:121-125
             return False
         self.tris = np.ascontiguousarray(a.reshape(-1, 12))
+        self.layout = 0
+        return True
+
+    def upload_scene_edges(self, float4s):
+        """(v0, e0, e1) rows with packed vertex normals in .w (Documentation/gpu.meshes.txt:16-34)."""
+        if not self.upload_scene(float4s):
+            return False
+        self.layout = 1
         return True
 
     def upload_spheres(self, float4s):
@@ -207,7 +246,8 @@ class OracleTracer:
         lib().orc_camera_rotate(C.byref(self.cam), _fp(_f32(dangles)))
 
     def _scene(self):
-        return Scene(_fp(self.tris), self.tris.shape[0], _fp(self.spheres), self.spheres.shape[0], self.hit_mode)
+        return Scene(_fp(self.tris), self.tris.shape[0], _fp(self.spheres), self.spheres.shape[0], self.hit_mode,
+                     self.layout, self.shade_mode)
 
     def launch(self, samples):
         sc = self._scene()

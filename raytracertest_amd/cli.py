@@ -28,7 +28,10 @@ def build_parser():
     p.add_argument("--aperture", type=float, default=4.0)
     p.add_argument("--cxa-rad", type=float, default=None)
     p.add_argument("--cya-rad", type=float, default=None)
-    p.add_argument("--scene", default="demo3", help="demo3 | cornell32 | rand10k | sphere1 | <file.f4> (raw float32 x,y,z,w)")
+    p.add_argument("--scene", default="demo3", help="demo3 | cornell32 | rand10k | sphere1 | uvsphere | <file.f4> (raw float32 x,y,z,w)")
+    p.add_argument("--edges", action="store_true", help="the scene file holds (v0, e0, e1) rows with packed vertex normals in .w")
+    p.add_argument("--smooth", action="store_true", help="shade with the interpolated vertex normals (edge-format scenes)")
+    p.add_argument("--nearest", action="store_true", help="keep the nearest hit with t > 0 instead of the reference's farthest")
     p.add_argument("--seed", type=int, default=None)
     p.add_argument("-o", default="image0.bmp", dest="out")
     p.add_argument("-q", action="store_true", dest="quiet")
@@ -47,6 +50,9 @@ def load_scene(name):
         return scenes.random_triangles(10000, 12345), z
     if name == "sphere1":
         return scenes.sphere1()
+    if name == "uvsphere":                   # edge format with vertex normals: use with --edges [--smooth]
+        from . import meshes
+        return meshes.uv_sphere(n_lat=12, n_lon=24), z
     return np.fromfile(name, dtype="<f4").reshape(-1, 4), z
 
 
@@ -62,8 +68,8 @@ def main(argv=None):
     aperture = float(a.aperture_i) if a.aperture_i is not None else a.aperture
     tris, spheres = load_scene(a.scene)
     g = RayTracer((a.w, a.height), (a.cx, a.cy, a.cz), (float(cxa), float(cya)), fov, focal, aperture,
-                  seed=a.seed, device=a.device)
-    if tris.shape[0] and not g.UploadScene(tris):
+                  seed=a.seed, device=a.device, nearest_hit=a.nearest, smooth_normals=a.smooth)
+    if tris.shape[0] and not (g.UploadSceneEdges if a.edges else g.UploadScene)(tris):
         sys.exit("scene '%s' has %d float4 (need a positive multiple of 3)" % (a.scene, tris.shape[0]))
     if spheres.shape[0]:
         g.UploadSpheres(spheres)

@@ -111,6 +111,16 @@ __device__ __forceinline__ void uniform_on_disk(Rng& s, float& dx, float& dy) {
   dy = sr * sn;
 }
 
+// Corrected form of the reference's experimental normal packing (UnitTests/NormalPackingTest.cpp:10-23,
+// Documentation/gpu.meshes.txt:20-33): n_k = floor(fract(packed * 256^k) * 256) / 127 - 1
+__device__ __forceinline__ V3 unpack_normal(float packed) {
+  auto field = [packed](float shift) {
+    const float s = packed * shift;
+    return __builtin_floorf((s - __builtin_floorf(s)) * 256.0f) / 127.0f - 1.0f;
+  };
+  return {field(1.0f), field(256.0f), field(65536.0f)};
+}
+
 // float -> rt::Channel as the GPU conversion does it: truncate toward zero, clamp, NaN -> 0
 __device__ __forceinline__ uint32_t to_channel(float f) {
   if (!(f > 0.0f)) return 0u;

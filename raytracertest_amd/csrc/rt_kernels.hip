@@ -64,7 +64,8 @@ template <bool FMA>
 __global__ __launch_bounds__(256) void prep_triangles_kernel(const float4* __restrict__ verts, uint32_t n, bool edges,
                                                               float4* __restrict__ tri_a,
                                                               float* __restrict__ tri_b,
-                                                              float4* __restrict__ color) {
+                                                              float4* __restrict__ color,
+                                                              float4* __restrict__ normals) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
   const float4 a = verts[3 * i + 0], b = verts[3 * i + 1], c = verts[3 * i + 2];
@@ -76,6 +77,12 @@ __global__ __launch_bounds__(256) void prep_triangles_kernel(const float4* __res
   tri_b[i] = v0.z;
   const V3 nn = Math<FMA>::normalize(Math<FMA>::cross(e1, e2));
   color[i] = make_float4(rtd::absf(nn.x), rtd::absf(nn.y), rtd::absf(nn.z), 0.0f);
+  if (normals != nullptr) {            // edge-format rows carry a packed vertex normal in .w
+    const V3 n0 = rtd::unpack_normal(a.w), n1 = rtd::unpack_normal(b.w), n2 = rtd::unpack_normal(c.w);
+    normals[3 * i + 0] = make_float4(n0.x, n0.y, n0.z, 0.0f);
+    normals[3 * i + 1] = make_float4(n1.x, n1.y, n1.z, 0.0f);
+    normals[3 * i + 2] = make_float4(n2.x, n2.y, n2.z, 0.0f);
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -196,10 +203,10 @@ hipError_t launch_rng_init(uint32_t* rng, uint32_t npix, uint32_t p0, const uint
 }
 
 hipError_t launch_prep_triangles(bool fma, bool edges, const float4* verts, uint32_t n, float4* tri_a, float* tri_b,
-                                 float4* color, hipStream_t st) {
+                                 float4* color, float4* normals, hipStream_t st) {
   if (n == 0) return hipSuccess;
-  if (fma) hipLaunchKernelGGL(prep_triangles_kernel<true>, dim3(cdiv(n, 256)), dim3(256), 0, st, verts, n, edges, tri_a, tri_b, color);
-  else hipLaunchKernelGGL(prep_triangles_kernel<false>, dim3(cdiv(n, 256)), dim3(256), 0, st, verts, n, edges, tri_a, tri_b, color);
+  if (fma) hipLaunchKernelGGL(prep_triangles_kernel<true>, dim3(cdiv(n, 256)), dim3(256), 0, st, verts, n, edges, tri_a, tri_b, color, normals);
+  else hipLaunchKernelGGL(prep_triangles_kernel<false>, dim3(cdiv(n, 256)), dim3(256), 0, st, verts, n, edges, tri_a, tri_b, color, normals);
   return hipGetLastError();
 }
 

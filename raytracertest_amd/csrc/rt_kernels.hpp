@@ -29,6 +29,7 @@ struct TraceParams {
   uint32_t  block_list;     // block-level pre-cull list (indices) in LDS; 0 = every wave scans the scene
   unsigned long long* stats; // null in the product path; 16 counters for the instrumented launch
   uint32_t* image;     // rows*W BGRA8, written when flags & TRACE_EMIT_IMAGE (mImageBuffer)
+  const float4* tri_n; // 3 per triangle: unpacked vertex normals (edge-format scenes with smooth shading), or null
   uint32_t* tile_lists; // per wave tile: count + bin_list triangle indices (TRACE_LISTS_*), or null
   uint32_t  flags;     // TRACE_*
 };
@@ -48,7 +49,7 @@ constexpr uint32_t TRACE_LISTS_LOAD = 16u;
 hipError_t launch_rng_init(uint32_t* rng, uint32_t npix, uint32_t p0, const uint32_t seeded[6],
                            const uint32_t* jump, hipStream_t st);
 hipError_t launch_prep_triangles(bool fma, bool edges, const float4* verts, uint32_t n, float4* tri_a, float* tri_b,
-                                 float4* color, hipStream_t st);
+                                 float4* color, float4* normals, hipStream_t st);
 uint32_t trace_lds_bytes(const TraceParams& p, bool bin);
 // bin: per-tile triangle classification + per-wave LDS candidate lists (rt_trace.hpp);
 // !bin: every ray scans the whole list, staged into LDS in chunks of p.chunk.

@@ -655,8 +655,32 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
         float r, g, b;
         if (win >= 0) {
           if (win < static_cast<int>(n)) {
-            const float4 col = p.tri_color[win];
-            r = col.x; g = col.y; b = col.z;
+            if (p.tri_n != nullptr) {
+              // build-defined smooth shading: vertex normals interpolated at the winner's barycentrics;
+              // u, v are recomputed from the winner's record (same arithmetic as the scan: same bits)
+              const float4 A0 = p.tri_a[2 * win], A1 = p.tri_a[2 * win + 1];
+              float t = 0.0f, u = 0.0f, v = 0.0f;
+              int stage;
+              (void)hit_triangle_exact<FMA>(o[k], d[k], {A1.z, A1.w, p.tri_b[win]}, {A0.w, A1.x, A1.y},
+                                            {A0.x, A0.y, A0.z}, RT_EPS, t, u, v, stage);
+              const float4 n0 = p.tri_n[3 * win], n1 = p.tri_n[3 * win + 1], n2 = p.tri_n[3 * win + 2];
+              const float w = (1.0f - u) - v;
+              V3 m;
+              if constexpr (FMA) {
+                m.x = __builtin_fmaf(v, n2.x, __builtin_fmaf(u, n1.x, w * n0.x));
+                m.y = __builtin_fmaf(v, n2.y, __builtin_fmaf(u, n1.y, w * n0.y));
+                m.z = __builtin_fmaf(v, n2.z, __builtin_fmaf(u, n1.z, w * n0.z));
+              } else {
+                m.x = (w * n0.x + u * n1.x) + v * n2.x;
+                m.y = (w * n0.y + u * n1.y) + v * n2.y;
+                m.z = (w * n0.z + u * n1.z) + v * n2.z;
+              }
+              const V3 nn = M::normalize(m);
+              r = rtd::absf(nn.x); g = rtd::absf(nn.y); b = rtd::absf(nn.z);
+            } else {
+              const float4 col = p.tri_color[win];
+              r = col.x; g = col.y; b = col.z;
+            }
           } else {
             const float4 sph = p.spheres[win - static_cast<int>(n)];
             const V3 hp = {M::madd1(d[k].x, dist, o[k].x), M::madd1(d[k].y, dist, o[k].y),

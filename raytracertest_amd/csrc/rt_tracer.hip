@@ -121,6 +121,8 @@ struct rt_tracer {
   bool band_mode = false;
   uint64_t seed = 1;
   bool fma = true, filter = true, bin = true, nearest_hit = false;
+  bool smooth_normals = false;        // RT_FLAG_SMOOTH_NORMALS; takes effect for edge-format scenes
+  float4* d_tri_n = nullptr;          // 3 unpacked vertex normals per triangle, edge-format scenes only
   uint32_t k_req = 0, chunk_req = 0, bin_list_req = 0;
 
   // device state
@@ -221,6 +223,7 @@ struct rt_tracer {
     p.aspect = static_cast<float>(W) / static_cast<float>(H);            // ThinLensCamera.cuh:113
     p.focal = c.focal; p.aperture = c.aperture;
     p.tri_a = d_tri; p.tri_b = d_tri_b; p.tri_color = d_tri_color; p.n_tris = n_tris;
+    p.tri_n = smooth_normals ? d_tri_n : nullptr;
     p.stats = nullptr;
     p.spheres = d_spheres; p.n_spheres = n_spheres;
     p.chunk = chunk_req ? chunk_req : 1024u;
@@ -531,6 +534,7 @@ int rt_tracer_create_ex(const uint32_t imageSize[2], const float cameraPosition[
   t->filter = (opt.flags & RT_FLAG_NO_FILTER) == 0;
   t->bin = (opt.flags & RT_FLAG_NO_BINNING) == 0;
   t->nearest_hit = (opt.flags & RT_FLAG_NEAREST_HIT) != 0;
+  t->smooth_normals = (opt.flags & RT_FLAG_SMOOTH_NORMALS) != 0;
   t->k_req = opt.samples_in_flight;
   t->chunk_req = opt.lds_chunk;
   t->bin_list_req = opt.bin_list;
@@ -575,6 +579,7 @@ void rt_tracer_destroy(rt_tracer* t) {                                   // RayT
   t->drain_events();
   for (EventPair& e : t->free_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (t->d_tile_lists) (void)hipFree(t->d_tile_lists);
+  if (t->d_tri_n) (void)hipFree(t->d_tri_n);
   if (t->d_tri) (void)hipFree(t->d_tri);
   if (t->d_tri_b) (void)hipFree(t->d_tri_b);
   if (t->d_tri_color) (void)hipFree(t->d_tri_color);
@@ -657,15 +662,17 @@ static int upload_scene_impl(rt_tracer* t, const rt_float4* hostData, size_t cou
     if (t->d_tri) { (void)hipFree(t->d_tri); t->d_tri = nullptr; }       // :128-137
     if (t->d_tri_b) { (void)hipFree(t->d_tri_b); t->d_tri_b = nullptr; }
     if (t->d_tri_color) { (void)hipFree(t->d_tri_color); t->d_tri_color = nullptr; }
+    if (t->d_tri_n) { (void)hipFree(t->d_tri_n); t->d_tri_n = nullptr; }
     t->n_tris = 0;
     const uint32_t n = static_cast<uint32_t>(count / 3);                 // :139
     DevBuf verts(count * sizeof(float4));
     HIP_CHECK(hipMalloc(&t->d_tri, static_cast<size_t>(n) * 2 * sizeof(float4)));
     HIP_CHECK(hipMalloc(&t->d_tri_b, static_cast<size_t>(n) * sizeof(float)));
     HIP_CHECK(hipMalloc(&t->d_tri_color, static_cast<size_t>(n) * sizeof(float4)));
+    if (edges) HIP_CHECK(hipMalloc(&t->d_tri_n, static_cast<size_t>(n) * 3 * sizeof(float4)));
     HIP_CHECK(hipMemcpyAsync(verts.p, hostData, count * sizeof(float4), hipMemcpyHostToDevice, t->stream));
     HIP_CHECK(rtk::launch_prep_triangles(t->fma, edges, verts.as<float4>(), n, t->d_tri, t->d_tri_b,
-                                         t->d_tri_color, t->stream));
+                                         t->d_tri_color, t->d_tri_n, t->stream));
     HIP_CHECK(hipStreamSynchronize(t->stream));
     t->n_tris = n;
     t->scene_generation++;

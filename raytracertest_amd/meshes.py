@@ -43,3 +43,30 @@ def to_edge_format(vertices, normals=None):
 def vertex_normals(edge_rows):
     """(3N, 4) edge-format rows -> (3N, 3) unpacked per-vertex normals."""
     return unpack_normal(np.ascontiguousarray(edge_rows, F).reshape(-1, 4)[:, 3])
+
+
+def uv_sphere(center=(0.0, 0.0, -4.0), radius=1.0, n_lat=8, n_lon=16):
+    """A latitude/longitude tessellation of a sphere in edge format with per-vertex normals
+    (the outward unit normals, quantised by the packing), wound so that the outside faces
+    have det > 0 for rays arriving from outside (Kernels.cuh:39-45).  2*n_lon*(n_lat-1) triangles."""
+    c = np.asarray(center, np.float64)
+
+    def vert(i, j):
+        th = np.pi * i / n_lat                # polar angle from +y
+        ph = 2.0 * np.pi * (j % n_lon) / n_lon
+        n = np.array([np.sin(th) * np.cos(ph), np.cos(th), np.sin(th) * np.sin(ph)])
+        return c + radius * n, n
+
+    tris, nrm = [], []
+    for i in range(n_lat):
+        for j in range(n_lon):
+            quad = [vert(i, j), vert(i + 1, j), vert(i + 1, j + 1), vert(i, j + 1)]
+            for (a, b, d) in ((0, 2, 1), (0, 3, 2)):
+                if (i == 0 and (a, b, d) == (0, 3, 2)) or (i == n_lat - 1 and (a, b, d) == (0, 2, 1)):
+                    continue                  # degenerate at the poles
+                tris.append([quad[a][0], quad[b][0], quad[d][0]])
+                nrm.append([quad[a][1], quad[b][1], quad[d][1]])
+    t = np.asarray(tris, F)
+    rows = np.zeros((t.shape[0], 3, 4), F)
+    rows[:, :, :3] = t
+    return to_edge_format(rows.reshape(-1, 4), normals=np.asarray(nrm, F).reshape(-1, 3))

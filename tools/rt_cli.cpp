@@ -26,7 +26,7 @@ struct Args {
   float cx = 0, cy = 0, cz = 0, cxa = 0, cya = 0, fov = 70.0f, focal = 10.0f, aperture = 4.0f;
   uint64_t seed = 0; bool have_seed = false;
   std::string scene = "demo3", scene_file, out = "image0.bmp";
-  bool quiet = false;
+  bool quiet = false, edges = false, smooth = false, nearest = false;
 };
 
 std::vector<float4> demo3() {                   // MainFrame.cpp:230-232
@@ -51,7 +51,8 @@ void usage() {
   std::puts("rt_cli [-w W] [-h H] [-s samples] [-i iterations] [-u updateInterval] [-cx N -cy N -cz N]\n"
             "       [-cxa deg] [-cya deg] [-f fovDeg] [-l focalLength] [-a aperture]      (reference flags, integers)\n"
             "       [--focal F] [--aperture A] [--fov F]                                  (float forms)\n"
-            "       [--scene demo3|<file.f4>] [--seed N] [-o out.bmp] [-q]");
+            "       [--scene demo3|<file.f4>] [--seed N] [-o out.bmp] [-q]\n"
+            "       [--edges] (file holds (v0,e0,e1) rows, packed vertex normals in .w)  [--smooth] [--nearest]");
 }
 
 }  // namespace
@@ -84,6 +85,9 @@ int main(int argc, char** argv) {
     else if (k == "--cya-rad") a.cya = std::strtof(next("--cya-rad"), nullptr);
     else if (k == "--scene") a.scene = next("--scene");
     else if (k == "--seed") { a.seed = std::strtoull(next("--seed"), nullptr, 10); a.have_seed = true; }
+    else if (k == "--edges") a.edges = true;
+    else if (k == "--smooth") a.smooth = true;
+    else if (k == "--nearest") a.nearest = true;
     else if (k == "-o") a.out = next("-o");
     else if (k == "-q") a.quiet = true;
     else if (k == "-v") a.quiet = false;
@@ -91,8 +95,13 @@ int main(int argc, char** argv) {
     else { std::fprintf(stderr, "unknown option %s\n", k.c_str()); usage(); return 2; }
   }
 
+  rt_options opt;
+  std::memset(&opt, 0, sizeof opt);
+  opt.struct_size = sizeof opt;
+  opt.use_time_seed = 1;                                       // Random.cu:45 unless --seed is given
+  opt.flags = (a.smooth ? RT_FLAG_SMOOTH_NORMALS : 0u) | (a.nearest ? RT_FLAG_NEAREST_HIT : 0u);
   rt::RayTracer tracer(math::uvec2(a.w, a.h), math::vec3(a.cx, a.cy, a.cz), math::vec2(a.cxa, a.cya), a.fov, a.focal,
-                       a.aperture);
+                       a.aperture, &opt);
   if (!tracer.Valid()) { std::fprintf(stderr, "rt_cli: %s\n", tracer.LastError().c_str()); return 1; }
   if (a.have_seed) tracer.SetSeed(a.seed);
 
@@ -101,7 +110,8 @@ int main(int argc, char** argv) {
     std::fprintf(stderr, "rt_cli: scene '%s' has %zu float4 (need a positive multiple of 3)\n", a.scene.c_str(), scene.size());
     return 1;
   }
-  tracer.UploadScene(scene);
+  if (a.edges) tracer.UploadSceneEdges(scene);
+  else tracer.UploadScene(scene);
 
   uint32_t updates = 0;
   std::vector<rt::Color> finalImage;
