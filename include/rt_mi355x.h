@@ -191,6 +191,10 @@ int rt_dbg_trace_occupancy(int device, int samples_in_flight, uint32_t lds_bytes
 /* fp32 VALU calibration on this device: attainable lane-FMA/s (8 fma chains per lane,
  * 8 waves per SIMD, every CU) and the shader clock held meanwhile.  Measurement aid only. */
 int rt_dbg_valu_peak(int device, double* lane_fma_per_s, double* clock_ghz);
+/* Exhaustive device check of the mid-range sqrt / reciprocal fast paths used by normalize: every float in
+ * [2^-96, 2^96] against the generic correctly rounded expansions.  out = {values checked, sqrt mismatches,
+ * reciprocal mismatches, bit pattern of a mismatching operand or 0}. */
+int rt_dbg_check_midrange(int device, uint64_t out[4]);
 /* states n*6 {d,v0..v4} advanced in place, out n*m uniforms in (0,1] */
 int rt_dbg_uniform(int device, uint32_t n, uint32_t m, uint32_t* states, float* out);
 /* thin-lens rays of the tracer's current camera for n (x, y) pixels with given RNG states */

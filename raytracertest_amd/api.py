@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "rt_tracer_stream",
     "rt_tracer_device_pointer", "rt_tracer_buffer_bytes", "rt_tracer_info",
     "rt_tracer_last_error", "rt_last_error", "rt_device_count", "rt_version",
-    "rt_dbg_hit_triangle", "rt_dbg_sincos", "rt_dbg_valu_peak", "rt_dbg_trace_occupancy", "rt_dbg_uniform", "rt_dbg_get_ray",
+    "rt_dbg_hit_triangle", "rt_dbg_sincos", "rt_dbg_valu_peak", "rt_dbg_check_midrange", "rt_dbg_trace_occupancy", "rt_dbg_uniform", "rt_dbg_get_ray",
     "rt_dbg_rng_init_host",
 ]
 
@@ -400,6 +400,18 @@ def dbg_valu_peak(device=0):
     if rc != 0:
         raise RtError("rt_dbg_valu_peak failed (%d): %s" % (rc, L.rt_last_error().decode()))
     return r.value, g.value
+
+
+def dbg_check_midrange(device=0):
+    """Exhaustive device check of normalize's mid-range sqrt/reciprocal fast paths:
+    (values checked, sqrt mismatches, reciprocal mismatches, a mismatching operand's bits or 0)."""
+    L = load_library()
+    out = (C.c_uint64 * 4)()
+    L.rt_dbg_check_midrange.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
+    rc = L.rt_dbg_check_midrange(device, out)
+    if rc != 0:
+        raise RtError("rt_dbg_check_midrange failed (%d): %s" % (rc, L.rt_last_error().decode()))
+    return tuple(int(x) for x in out)
 
 
 def dbg_uniform(states, m, device=0):

@@ -20,6 +20,33 @@ __device__ __forceinline__ V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.
 __device__ __forceinline__ V3 add(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 __device__ __forceinline__ float absf(float f) { return (f < 0.0f) ? -f : f; }   // Kernels.cuh:16-19
 
+// ---- correctly rounded sqrt and reciprocal for operands in [2^-96, 2^96] ------------------------
+// The compiler's IEEE expansions of sqrtf (17 instructions) and 1.0f/y (12) spend 7 and 5 of
+// them on operand scaling (denormal and overflow ranges) and special values.  For mid-range
+// operands those steps are no-ops; what remains is reproduced here instruction for instruction.
+__device__ __forceinline__ bool midrange(float x) {                 // 2^-96 <= x <= 2^96 (false for NaN, inf, <= 0)
+  return (__builtin_bit_cast(uint32_t, x) - 0x0F800000u) <= (0x6F800000u - 0x0F800000u);
+}
+__device__ __forceinline__ float sqrt_midrange(float x) {
+  const float s = __builtin_amdgcn_sqrtf(x);                        // v_sqrt_f32, 1 ulp
+  const float s_dn = __builtin_bit_cast(float, __builtin_bit_cast(int, s) - 1);
+  const float s_up = __builtin_bit_cast(float, __builtin_bit_cast(int, s) + 1);
+  const float r_dn = __builtin_fmaf(-s_dn, s, x);
+  const float r_up = __builtin_fmaf(-s_up, s, x);
+  float r = (r_dn <= 0.0f) ? s_dn : s;
+  r = (r_up > 0.0f) ? s_up : r;
+  return r;
+}
+__device__ __forceinline__ float rcp_midrange(float y) {
+  float r = __builtin_amdgcn_rcpf(y);                               // v_rcp_f32, 1 ulp
+  const float e0 = __builtin_fmaf(-y, r, 1.0f);
+  r = __builtin_fmaf(e0, r, r);
+  const float e1 = __builtin_fmaf(-y, r, 1.0f);                     // numerator 1: the quotient estimate is r itself
+  const float q = __builtin_fmaf(e1, r, r);
+  const float e2 = __builtin_fmaf(-y, q, 1.0f);
+  return __builtin_fmaf(e2, r, q);
+}
+
 template <bool FMA>
 struct Math {
   // x*y - z*w
@@ -46,9 +73,18 @@ struct Math {
     if constexpr (FMA) return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.x, b.x, a.y * b.y));
     else return ((a.x * b.x) + (a.y * b.y)) + (a.z * b.z);
   }
-  // glm::normalize: v * (1 / sqrt(dot(v, v)))
+  // glm::normalize: v * (1 / sqrt(dot(v, v))), both operations correctly rounded.  When every
+  // active lane's squared length lies in [2^-96, 2^96] (wave-uniform test; always, in practice) the
+  // scaling and special-case steps of the generic expansions are skipped: same bits, 13 fewer
+  // VALU instructions per ray (device-checked over every float of the range, rt_dbg_check_midrange).
   static __device__ __forceinline__ V3 normalize(V3 a) {
-    const float inv = 1.0f / __builtin_sqrtf(dot(a, a));
+    const float dd = dot(a, a);
+    float inv;
+#ifndef RT_NO_MIDRANGE
+    if (__builtin_amdgcn_ballot_w64(!midrange(dd)) == 0ull) inv = rcp_midrange(sqrt_midrange(dd));
+    else
+#endif
+      inv = 1.0f / __builtin_sqrtf(dd);
     return {a.x * inv, a.y * inv, a.z * inv};
   }
   // glm mat4 * vec4, xyz: (m0*x + m1*y) + (m2*z + m3*w); M holds the 4 columns' xyz

@@ -283,6 +283,32 @@ hipError_t launch_dbg_hit_triangle(bool fma, uint32_t n, const float* rays, cons
   return hipGetLastError();
 }
 
+// every float in [2^-96, 2^96]: sqrt_midrange / rcp_midrange against the generic expansions
+__global__ __launch_bounds__(256) void dbg_check_midrange_kernel(unsigned long long* __restrict__ out) {
+  const uint32_t first = 0x0F800000u, last = 0x6F800000u;
+  unsigned long long bad_sqrt = 0, bad_rcp = 0, seen = 0;
+  uint32_t first_bad = 0;
+  for (unsigned long long b = first + static_cast<unsigned long long>(blockIdx.x) * 256u + threadIdx.x; b <= last;
+       b += static_cast<unsigned long long>(gridDim.x) * 256u) {
+    const float x = __builtin_bit_cast(float, static_cast<uint32_t>(b));
+    const float s0 = __builtin_sqrtf(x), s1 = rtd::sqrt_midrange(x);
+    const float r0 = 1.0f / x, r1 = rtd::rcp_midrange(x);
+    const bool bs = __builtin_bit_cast(uint32_t, s0) != __builtin_bit_cast(uint32_t, s1);
+    const bool br = __builtin_bit_cast(uint32_t, r0) != __builtin_bit_cast(uint32_t, r1);
+    bad_sqrt += bs; bad_rcp += br; seen += rtd::midrange(x) ? 1u : 0u;
+    if ((bs || br) && first_bad == 0u) first_bad = static_cast<uint32_t>(b);
+  }
+  atomicAdd(out + 0, seen);
+  atomicAdd(out + 1, bad_sqrt);
+  atomicAdd(out + 2, bad_rcp);
+  if (first_bad != 0u) atomicMax(out + 3, static_cast<unsigned long long>(first_bad));
+}
+
+hipError_t launch_dbg_check_midrange(unsigned long long* out, hipStream_t st) {
+  hipLaunchKernelGGL(dbg_check_midrange_kernel, dim3(8192), dim3(256), 0, st, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_dbg_valu_peak(uint32_t blocks, int iters, float* out, unsigned long long* clk, hipStream_t st) {
   hipLaunchKernelGGL(dbg_valu_peak_kernel, dim3(blocks), dim3(256), 0, st, out, iters, clk);
   return hipGetLastError();

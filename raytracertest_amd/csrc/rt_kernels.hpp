@@ -30,6 +30,9 @@ struct TraceParams {
   unsigned long long* stats; // null in the product path; 16 counters for the instrumented launch
   uint32_t* image;     // rows*W BGRA8, written when flags & TRACE_EMIT_IMAGE (mImageBuffer)
   const float4* tri_n; // 3 per triangle: unpacked vertex normals (edge-format scenes with smooth shading), or null
+#ifdef RT_TIMELINE
+  unsigned long long* timeline;   // experiment builds only (tools/timeline.py): 8 u64 per wave
+#endif
   uint32_t* tile_lists; // per wave tile: count + bin_list triangle indices (TRACE_LISTS_*), or null
   uint32_t  flags;     // TRACE_*
 };
@@ -60,6 +63,7 @@ hipError_t launch_convert(const float4* render, const uint32_t* counts, uint32_t
 
 hipError_t launch_dbg_hit_triangle(bool fma, uint32_t n, const float* rays, const float* tris, int eps_mode,
                                    int* hit, float* tuv, float* normal, float* point, hipStream_t st);
+hipError_t launch_dbg_check_midrange(unsigned long long* out, hipStream_t st);
 hipError_t launch_dbg_valu_peak(uint32_t blocks, int iters, float* out, unsigned long long* clk, hipStream_t st);
 hipError_t launch_dbg_sincos(uint32_t n, const float* x, float* s, float* c, hipStream_t st);
 hipError_t launch_dbg_uniform(uint32_t n, uint32_t m, uint32_t* states, float* out, hipStream_t st);

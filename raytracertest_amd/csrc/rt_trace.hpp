@@ -271,6 +271,9 @@ struct TileFamily {
 __device__ __forceinline__ float uniform(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
+// Wave-wide min/max through ds_bpermute (__shfl_xor).  A DPP/readlane butterfly was measured
+// SLOWER (C3 166.5 vs 163.3 us): the kernel is VALU-issue-bound, and the bpermute round trips run
+// on the otherwise idle LDS crossbar while other waves use the VALU.
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
@@ -403,6 +406,25 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   const uint32_t cxp = inside ? px : 0u, cyp = inside ? ly : 0u;   // out-of-image lanes shadow pixel 0
   const size_t pix = static_cast<size_t>(cxp) + static_cast<size_t>(cyp) * p.W;   // Kernels.cuh:128
 
+#ifdef RT_TIMELINE
+  // experiment builds only: per-wave timestamps (shader clock) + where the wave ran
+  const size_t tl_slot = ((static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 4u + wave) * 16u;
+  auto tl_mark = [&](uint32_t i) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (p.timeline != nullptr && lane == 0u) p.timeline[tl_slot + i] = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  if (p.timeline != nullptr && lane == 0u) {
+    uint32_t hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    p.timeline[tl_slot + 6] = hw;
+    p.timeline[tl_slot + 7] = (static_cast<unsigned long long>(xcc) << 32) | (__builtin_amdgcn_s_memrealtime() & 0xffffffffull);
+  }
+  tl_mark(0);
+#else
+  auto tl_mark = [](uint32_t) {};
+#endif
   Rng rng;                                                         // :131
   rng.d = p.rng[0 * static_cast<size_t>(p.npix) + pix];
   rng.v0 = p.rng[1 * static_cast<size_t>(p.npix) + pix];
@@ -411,14 +433,6 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   rng.v3 = p.rng[4 * static_cast<size_t>(p.npix) + pix];
   rng.v4 = p.rng[5 * static_cast<size_t>(p.npix) + pix];
 
-  // accumulator read issued up front so that its latency hides under the tracing (the +=
-  // at the end then only waits for an already-finished load; measured C3 212 -> 197 us)
-  float4 acc_in = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  uint32_t cnt_in = 0u;
-  if (!(p.flags & TRACE_ZERO_ACC)) {                                // wave-uniform
-    acc_in = p.render[pix];
-    cnt_in = p.counts[pix];
-  }
 
   V3 po, pd;
   pinhole<FMA>(p, cxp, p.row0 + cyp, po, pd);
@@ -451,6 +465,7 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   float4* const cA = s_mem + static_cast<size_t>(wave) * (2u * L);                         // 2 float4 per candidate
   float* const cB = reinterpret_cast<float*>(s_mem + 4u * 2u * L) + wave * L;
   int* const cI = reinterpret_cast<int*>(s_mem + 4u * 2u * L) + 4u * L + wave * L;
+
   TileFamily fam;
   bool list_complete = false;       // the list in LDS covers the whole scene (classification done once)
   uint32_t list_count = 0;
@@ -465,8 +480,12 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   uint32_t src_count = n;           // triangles the wave-level classification walks over
   bool src_is_block_list = false;
   if constexpr (BIN) {
+    tl_mark(8);                                                    // loads issued, pinhole + focal point done
     const FocalBounds wb = focal_bounds(focal, inside);
+    tl_mark(11);
+    tl_mark(9);
     fam = make_family(p, wb);
+    tl_mark(10);
     if constexpr (!ONEPASS) {
       if (Lb != 0u) {
         if (lane == 0u) {
@@ -530,8 +549,10 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
       const uint32_t ei = valid ? e : (src_count - 1u);
       const uint32_t tri = src_is_block_list ? bI[ei] : ei;
       const uint32_t ti = tri;
-      const float4 A0 = p.tri_a[2u * ti], A1 = p.tri_a[2u * ti + 1u];
-      const float bz = p.tri_b[ti];
+      float4 A0, A1;
+      float bz;
+      A0 = p.tri_a[2u * ti]; A1 = p.tri_a[2u * ti + 1u];
+      bz = p.tri_b[ti];
       bool keep = valid;
       if (fam.usable)
         keep = valid && !tile_misses_triangle(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z});
@@ -587,7 +608,9 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
     }
     list_complete = true;
   }
+  tl_mark(1);                                                      // family + classification done
   for (uint32_t s0 = 0; s0 < p.samples; s0 += K) {                 // :134, K samples per pass
+    if (s0 == static_cast<uint32_t>(K)) tl_mark(2);                // first batch done (includes the wait for the RNG state)
     V3 o[K], d[K];
     float best_t[K];
     int best_i[K];
@@ -704,7 +727,17 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
     }
   }
 
+  tl_mark(3);                                                      // all samples done
   if (inside) {
+    // Accumulators are read here, not prefetched at kernel start: five registers held across
+    // the whole kernel cost more (spills at the 96-VGPR budget of 5 waves/SIMD) than the exposed
+    // read latency of a finished wave (measured C3 169.4 -> 164.9 us, progressive launches equal).
+    float4 acc_in = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint32_t cnt_in = 0u;
+    if (!(p.flags & TRACE_ZERO_ACC)) {                              // wave-uniform
+      acc_in = p.render[pix];
+      cnt_in = p.counts[pix];
+    }
     const uint32_t cnt = cnt_in + p.samples;                        // :140
     p.counts[pix] = cnt;
     float4 acc = acc_in;
@@ -721,6 +754,7 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
     p.rng[4 * static_cast<size_t>(p.npix) + pix] = rng.v3;
     p.rng[5 * static_cast<size_t>(p.npix) + pix] = rng.v4;
   }
+  tl_mark(4);                                                      // stores issued
   if constexpr (STATS) {
     if (lane == 0 && p.stats != nullptr) {
 #pragma unroll

@@ -872,6 +872,20 @@ int rt_dbg_hit_triangle(int device, uint32_t math_mode, uint32_t n, const float*
   });
 }
 
+int rt_dbg_check_midrange(int device, uint64_t out[4]) {
+  if (!out) return RT_ERR_INVALID;
+  int rc = require_device(device);
+  if (rc != RT_OK) return rc;
+  return guarded(nullptr, [&] {
+    HIP_CHECK(hipSetDevice(device));
+    DevBuf d(4 * sizeof(unsigned long long));
+    HIP_CHECK(hipMemset(d.p, 0, 4 * sizeof(unsigned long long)));
+    HIP_CHECK(rtk::launch_dbg_check_midrange(d.as<unsigned long long>(), nullptr));
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(out, d.p, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  });
+}
+
 int rt_dbg_valu_peak(int device, double* lane_fma_per_s, double* clock_ghz) {
   int rc = require_device(device);
   if (rc != RT_OK) return rc;
@@ -899,6 +913,29 @@ int rt_dbg_valu_peak(int device, double* lane_fma_per_s, double* clock_ghz) {
     if (clock_ghz) *clock_ghz = c[1] ? static_cast<double>(c[0]) / static_cast<double>(c[1]) * 0.1 : 0.0;
   });
 }
+
+#ifdef RT_TIMELINE
+// experiment builds only (make EXTRA=-DRT_TIMELINE): one launch with per-wave timestamps
+extern "C" int rt_dbg_trace_timeline(rt_tracer* t, uint32_t samples, unsigned long long* out, size_t capacity_words) {
+  if (!t || !out) return RT_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(t->api_mu);
+  return guarded(t, [&] {
+    t->cancel_and_join();
+    t->use_device();
+    const size_t words = static_cast<size_t>((t->W + 31u) / 32u) * ((t->rows + 7u) / 8u) * 4u * 16u;
+    if (words > capacity_words) throw HipFail{fmt("timeline needs %zu words", words)};
+    DevBuf buf(words * sizeof(unsigned long long));
+    HIP_CHECK(hipMemsetAsync(buf.p, 0, words * sizeof(unsigned long long), t->stream));
+    rtk::TraceParams p = t->params(samples);
+    p.flags = rtk::TRACE_ZERO_ACC | rtk::TRACE_EMIT_IMAGE | (t->nearest_hit ? rtk::TRACE_NEAREST_HIT : 0u);
+    p.image = t->d_image;
+    p.timeline = buf.as<unsigned long long>();
+    HIP_CHECK(rtk::launch_trace(p, t->fma, t->filter, t->bin, t->pick_k(samples), t->stream));
+    HIP_CHECK(hipStreamSynchronize(t->stream));
+    HIP_CHECK(hipMemcpy(out, buf.p, words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  });
+}
+#endif
 
 int rt_dbg_trace_occupancy(int device, int samples_in_flight, uint32_t lds_bytes) {
   if (require_device(device) != RT_OK) return -1;

@@ -64,6 +64,15 @@ def test_hit_triangle_random_vs_oracle(rt, orc, mode):
     assert 500 < nh < n - 500
 
 
+def test_midrange_sqrt_and_reciprocal_are_exact_for_every_float_of_their_range(rt):
+    """normalize skips the scaling/special-case steps of the generic sqrt and division when the
+    squared length is in [2^-96, 2^96]: proven equal by enumeration of all 1.6e9 operands."""
+    from raytracertest_amd import api
+    seen, bad_sqrt, bad_rcp, example = api.dbg_check_midrange()
+    assert seen == 0x6F800000 - 0x0F800000 + 1
+    assert (bad_sqrt, bad_rcp) == (0, 0), "first mismatching operand bits: 0x%08x" % example
+
+
 def test_sincos_bitexact(rt, orc):
     x = np.concatenate([np.linspace(0, 6.2831309, 50001), np.linspace(-40, 40, 20001),
                         [0.0, 1e-30, 1.5707964, 3.1415927, 6.2831855]]).astype(np.float32)
