@@ -204,6 +204,23 @@ def main():
                                    "the reference's exit point (20/30/46/52, FMA = 2) + 100 per ray.  The kernel skips "
                                    "triangles its per-tile classification proves missed, so frac > what the VALU executes; "
                                    "attainable = 2 x lane-FMA/s of an 8-chain fma loop at 8 waves/SIMD on this device"}
+            # what the VALU actually issued (PMC pass of the same command, profiles/valu_issue.json) against
+            # the issue rate the calibration loop reaches on this device: the kernel's real bound
+            issued = None
+            try:
+                issued = json.load(open(os.path.join(ROOT, "profiles", "valu_issue.json")))[args.config]
+            except (OSError, KeyError, ValueError):
+                pass
+            if issued:
+                n_inst = issued["valu_wave_instructions_per_launch"]
+                rate_peak = lane_fma / 64.0                      # wave64 VALU instructions per second, whole device
+                out["valu"]["issue"] = {"valu_wave_instructions_per_launch": n_inst,
+                                        "lane_instructions_per_ray": round(n_inst * 64.0 / rays_per_gpu, 1),
+                                        "achieved_Ginst_s": round(n_inst / avg_kernel_s / 1e9, 2),
+                                        "attainable_Ginst_s": round(rate_peak / 1e9, 2),
+                                        "frac": round(n_inst / avg_kernel_s / rate_peak, 4),
+                                        "note": "SQ_INSTS_VALU per launch (rocprofv3 --pmc, own pass) / kernel time, against the "
+                                                "wave64 instruction rate of the fma calibration loop on this device"}
             g = R.RayTracer((cfg["width"], cfg["height"]), (0, 0, 0), cfg["angles"], cfg["fov"], cfg["focal"],
                             cfg["aperture"], seed=cfg["seed"], device=local_rank)
             if tris.shape[0]:

@@ -578,14 +578,15 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   // ONEPASS: the scene has no more triangles than the list holds (host-checked), so one
   // classification before any ray exists is enough; keeping it out of the sample loop saves
   // ~17 VGPRs (K = 2: 98 -> 96 with 5 waves/SIMD; measured C3 202 -> 192 us).
-  // Later launches of the same Trace (same camera, scene and frame: host-checked) reuse the
-  // tile's candidate list that the first launch stored in HBM instead of re-classifying: the
-  // list depends on the tile's ray family only, not on the samples.
+  // Accumulating launches (same camera, scene and frame: host-checked) reuse the tile's
+  // candidate list that the first of them stored in HBM instead of re-classifying: the list
+  // depends on the tile's ray family only, not on the samples.
   if constexpr (BIN && ONEPASS) {
     const size_t slot = (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 4u + wave;
     uint32_t* const saved = p.tile_lists + slot * (1u + L);
     if (p.flags & TRACE_LISTS_LOAD) {
-      const uint32_t count = saved[0];                              // wave-uniform
+      // wave-uniform by construction; readfirstlane tells the compiler (scalar loop control below)
+      const uint32_t count = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(saved[0])));
       for (uint32_t base = 0; base < count; base += 64u) {
         const uint32_t e = base + lane;
         if (e < count) {

@@ -320,10 +320,12 @@ struct rt_tracer {
     HIP_CHECK(hipStreamSynchronize(stream));                             // :259,:287
   }
 
-  // Candidate lists of a Trace's first launch are kept for its later launches (ONEPASS scenes):
-  // same camera snapshot, scene, frame and list length => same lists (they do not depend on the
-  // samples).  A launch that clears the accumulators starts a new Trace and always re-classifies,
-  // so single-launch passes (bench.py's step) never read a cached list.
+  // Candidate lists (ONEPASS scenes) are kept across launches: the launch that clears the
+  // accumulators (the first of a Trace) classifies as usual and stores nothing, so one-launch
+  // passes -- bench.py's step -- neither pay for nor profit from the cache; the first
+  // accumulating launch classifies and stores its tiles' lists, later ones load them as long as
+  // camera snapshot, scene, frame, list length and arithmetic mode are unchanged (they do not
+  // depend on the samples).
   struct ListKey {
     float cam[12], half_height, aspect, focal, aperture;
     uint32_t W, H, row0, rows, bin_list, n_tris, scene_generation;
@@ -337,6 +339,7 @@ struct rt_tracer {
 
   void attach_tile_lists(rtk::TraceParams& p, bool first_launch_of_trace) {
     p.tile_lists = nullptr;
+    if (first_launch_of_trace) return;    // plain classification, nothing stored: a one-launch Trace pays nothing
     if (!bin || p.n_tris == 0u || p.n_tris > p.bin_list || getenv("RT_MI355X_NO_LIST_REUSE")) return;
     const size_t tiles = static_cast<size_t>((W + 31u) / 32u) * ((rows + 7u) / 8u) * 4u;
     const size_t words = tiles * (1u + p.bin_list);
@@ -354,7 +357,7 @@ struct rt_tracer {
     k.scene_generation = scene_generation; k.fma = fma;
     p.tile_lists = d_tile_lists;
     const bool same = list_key_valid && memcmp(&k, &list_key, sizeof k) == 0;
-    if (!first_launch_of_trace && same) {
+    if (same) {
       p.flags |= rtk::TRACE_LISTS_LOAD;
     } else {
       p.flags |= rtk::TRACE_LISTS_STORE;

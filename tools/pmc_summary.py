@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Summarises gpurun_out/<tag>/ (tools/profile_round.sh) into profiles/: kernel stats CSV, bench lines,
+per-kernel means of the PMC passes, and the derived profiles/hbm_traffic.json + profiles/valu_issue.json
+that bench.py reads.  python tools/pmc_summary.py r01_f"""
+import collections, csv, glob, json, os, shutil, sys
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+src = os.path.join(root, "gpurun_out", tag)
+dst = os.path.join(root, "profiles")
+for name in ("bench_c3.json", "bench_c4.json", "bench_c3_under_rocprof.json"):
+    shutil.copy(os.path.join(src, name), os.path.join(dst, "%s_%s" % (tag, name)))
+stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
+shutil.copy(stats[0], os.path.join(dst, "%s_c3_kernel_stats.csv" % tag))
+rows = []
+means = {}
+for p in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    f = glob.glob(os.path.join(src, p, "*", "*counter_collection.csv"))[0]
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for (k, c), v in sorted(agg.items()):
+        rows.append([p, k, c, len(v), "%.1f" % (sum(v) / len(v)), "%.1f" % min(v), "%.1f" % max(v)])
+        means[(k, c)] = sum(v) / len(v)
+with open(os.path.join(dst, "%s_c3_pmc_summary.csv" % tag), "w", newline="") as f:
+    w = csv.writer(f); w.writerow(["pass", "kernel", "counter", "dispatches", "mean", "min", "max"]); w.writerows(rows)
+tk = [k for (k, c) in means if "trace_kernel" in k][0]
+fetch_kb, write_kb = means[(tk, "FETCH_SIZE")], means[(tk, "WRITE_SIZE")]
+npix = 1920 * 1080
+alg = npix * (2 * 24 + 32) + 48 * 32
+traffic = int(round((fetch_kb * 2.0 + write_kb) * 1024))
+json.dump({
+    "_method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a separate pass, --pmc WRITE_SIZE around `python3 bench.py --steps 5 --warmup 1 "
+               "--cpu-rows 0 --no-valu` (%s, tools/profile_round.sh). Counter unit KB; FETCH_SIZE x2 on gfx950 as MI355X_MICROARCH.md prescribes "
+               "(factor calibrated in round 1 on convert_kernel, profiles/r01_pmc_c3_fetch.csv). Per-kernel means: profiles/%s_c3_pmc_summary.csv." % (tag, tag),
+    "C3": {"bytes_per_launch": traffic, "fetch_size_kb_raw": round(fetch_kb, 1), "fetch_correction": 2.0, "write_size_kb": round(write_kb, 1),
+           "algorithmic_bytes_per_launch": alg,
+           "note": "bench launches treat the accumulators as zero (no accumulator read): reads = 24 B/pixel RNG state, writes = 24 B RNG + 16 B RGBA + 4 B count + 4 B BGRA8"}},
+    open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
+valu = means[(tk, "SQ_INSTS_VALU")]
+json.dump({
+    "_method": "rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE "
+               "(%s, own pass). Per-launch means for the C3 trace kernel; wave-level instruction counts (one count per wave64 instruction)." % tag,
+    "C3": {"valu_wave_instructions_per_launch": int(valu), "salu": int(means[(tk, "SQ_INSTS_SALU")]), "lds": int(means[(tk, "SQ_INSTS_LDS")]),
+           "waves": int(means[(tk, "SQ_WAVES")]), "valu_per_wave": round(valu / means[(tk, "SQ_WAVES")], 1),
+           "lane_instructions_per_ray": round(valu * 64 / (npix * 16), 1)}},
+    open(os.path.join(dst, "valu_issue.json"), "w"), indent=1)
+print("traffic %d B/launch (algorithmic %d), VALU wave-instructions/launch %d (%.0f per wave)" % (traffic, alg, valu, valu / means[(tk, "SQ_WAVES")]))
