@@ -329,8 +329,10 @@ __device__ __forceinline__ TileFamily make_family(const TraceParams& p, const Fo
     lmin2 = __builtin_fmaf(amin, amin, lmin2);
     lmax2 = __builtin_fmaf(amax, amax, lmax2);
   }
-  f.lmin = __builtin_sqrtf(lmin2) * 0.999998f;
-  f.lmax = __builtin_sqrtf(lmax2) * 1.000002f;
+  // conservative bounds, not results: the raw v_sqrt_f32 (1 ulp; a denormal operand may read as 0)
+  // under the 2e-6 slack and an absolute 1e-18 instead of two 17-instruction correctly rounded sqrtf
+  f.lmin = __builtin_amdgcn_sqrtf(lmin2) * 0.999998f;
+  f.lmax = __builtin_amdgcn_sqrtf(lmax2) * 1.000002f + 1e-18f;
   f.usable = b.ok && b.any && (A <= FLT_MAX) && (f.lmax <= FLT_MAX);
   return f;
 }
