@@ -484,7 +484,6 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   if constexpr (BIN) {
     tl_mark(8);                                                    // loads issued, pinhole + focal point done
     const FocalBounds wb = focal_bounds(focal, inside);
-    tl_mark(11);
     tl_mark(9);
     fam = make_family(p, wb);
     tl_mark(10);

@@ -12,10 +12,12 @@ from raytracertest_amd import api, scenes
 
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 scene = sys.argv[2] if len(sys.argv) > 2 else "cornell32"
-cfg = scenes.CONFIGS["C3"]
+cfg = scenes.CONFIGS["C4" if scene == "rand10k" else "C3"]
 g = R.RayTracer((cfg["width"], cfg["height"]), (0, 0, 0), cfg["angles"], cfg["fov"], cfg["focal"], cfg["aperture"], seed=1)
 if scene == "cornell32":
     g.UploadScene(scenes.cornell32())
+elif scene == "rand10k":
+    g.UploadScene(scenes.random_triangles(10000, 12345))
 for _ in range(5):
     g.TraceEnqueue(1, spp)
 g.Sync(); g.KernelTime()
@@ -47,11 +49,12 @@ print("kernel span %.1f us; wave lifetime mean %.2f us (p10 %.2f p50 %.2f p90 %.
 d = np.diff(us, axis=1)
 for i, nm in enumerate(["family+classify", "first batch (+RNG wait)", "other batches", "store issue"]):
     print("  %-26s mean %6.2f us  p10 %6.2f  p50 %6.2f  p90 %6.2f" % (nm, d[:, i].mean(), *np.percentile(d[:, i], [10, 50, 90])))
-pm = (t[:, [0, 8, 11, 9, 10, 1]].astype(np.int64) - t[:, [0]].astype(np.int64)) / 100.0
-for i, nm in enumerate(["loads + pinhole + focal", "focal_bounds (wave reductions)", "park first record (vmcnt wait)", "make_family", "classification"]):
+pm = (t[:, [0, 8, 9, 10, 1]].astype(np.int64) - t[:, [0]].astype(np.int64)) / 100.0
+for i, nm in enumerate(["state loads issued", "pinhole + focal point + wave bounds", "make_family", "classification"]):
     seg = pm[:, i + 1] - pm[:, i]
     print("    prologue: %-30s mean %6.2f us  p10 %6.2f  p90 %6.2f" % (nm, seg.mean(), *np.percentile(seg, [10, 90])))
-nb = (spp + 1) // 2
+KK = 2 if scene != 'rand10k' else 4
+nb = (spp + KK - 1) // KK
 if nb > 1:
     pb = d[:, 2] / (nb - 1)
     print("  per batch %.2f us; first-batch excess (exposed RNG wait) %.2f us" % (pb.mean(), (d[:, 1] - pb).mean()))
