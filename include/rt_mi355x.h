@@ -45,6 +45,8 @@ extern "C" {
 #define RT_FLAG_NEAREST_HIT 4u  /* hit selection extension: keep the nearest hit with t > 0 instead of the
                                   reference's farthest hit incl. negative t (Kernels.cuh:73,84).  Not the default. */
 
+#define RT_FLAG_NO_MACRO_BINS 16u /* disable the macro-tile level of the classification (large scenes): every block
+                                  pre-culls the whole triangle list (debug / parity tests / A-B) */
 #define RT_FLAG_SMOOTH_NORMALS 8u /* shading extension for scenes uploaded with rt_tracer_upload_scene_edges: the
                                   colour is |normalize(w*n0 + u*n1 + v*n2)|, the rows' packed vertex normals
                                   interpolated at the hit (w = (1-u)-v), instead of |face normal| (Kernels.cuh:97-99).

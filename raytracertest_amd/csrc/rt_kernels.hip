@@ -283,6 +283,14 @@ hipError_t launch_dbg_hit_triangle(bool fma, uint32_t n, const float* rays, cons
   return hipGetLastError();
 }
 
+hipError_t launch_macro_bin(const TraceParams& p, bool fma, hipStream_t st) {
+  if (p.macro_lists == nullptr || p.n_tris == 0u || p.rows == 0u || p.W == 0u) return hipSuccess;
+  const dim3 grid(cdiv(p.W, p.macro_w), cdiv(p.rows, p.macro_h));
+  if (fma) hipLaunchKernelGGL(macro_bin_kernel<true>, grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(macro_bin_kernel<false>, grid, dim3(256), 0, st, p);
+  return hipGetLastError();
+}
+
 // every float in [2^-96, 2^96]: sqrt_midrange / rcp_midrange against the generic expansions
 __global__ __launch_bounds__(256) void dbg_check_midrange_kernel(unsigned long long* __restrict__ out) {
   const uint32_t first = 0x0F800000u, last = 0x6F800000u;

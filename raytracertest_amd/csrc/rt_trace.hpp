@@ -396,6 +396,91 @@ __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0,
 // Dynamic LDS: BIN ? 4 waves * bin_list * 40 bytes (+ block_list * 4 + 160 bytes for the block-level
 // pre-cull) : min(n_tris, chunk) * 36 bytes.
 // ------------------------------------------------------------------------------------
+// Macro level of the triangle classification (scenes larger than the per-wave list).
+// One block per macro tile of macro_w x macro_h pixels (whole trace blocks): the focal points of
+// ALL its pixels, computed exactly as the trace kernel computes them, give the macro tile's ray
+// family; every triangle the family certainly misses is dropped, the survivors' indices are
+// written in ascending order.  The trace kernel's blocks then pre-cull their macro tile's list
+// instead of the whole scene (C4: ~40 steps of 256 triangles per block -> 1-2).  Same
+// conservative test as the block and wave levels, so the result stays bit-identical to the
+// full scan.  Runs once per launch (the camera may have changed): N x macro tiles tests.
+// ------------------------------------------------------------------------------------
+template <bool FMA>
+__global__ __launch_bounds__(256) void macro_bin_kernel(TraceParams p) {
+  __shared__ float s_box[4][8];
+  __shared__ uint32_t s_cnt[2][4];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t x0 = blockIdx.x * p.macro_w, y0 = blockIdx.y * p.macro_h;
+  const uint32_t x1 = (x0 + p.macro_w < p.W) ? x0 + p.macro_w : p.W;
+  const uint32_t y1 = (y0 + p.macro_h < p.rows) ? y0 + p.macro_h : p.rows;
+  const uint32_t w = x1 - x0, count_px = w * (y1 - y0);
+  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  bool finite = true;
+  for (uint32_t i = threadIdx.x; i < count_px; i += 256u) {
+    const uint32_t px = x0 + i % w, ly = y0 + i / w;
+    V3 po, pd;
+    pinhole<FMA>(p, px, p.row0 + ly, po, pd);
+    const V3 f = focal_point<FMA>(p, pd);
+    const float fl[3] = {f.x, f.y, f.z};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      finite = finite && (__builtin_fabsf(fl[c]) <= FLT_MAX);
+      lo[c] = fminf(lo[c], fl[c]);
+      hi[c] = fmaxf(hi[c], fl[c]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { lo[c] = uniform(wave_min(lo[c])); hi[c] = uniform(wave_max(hi[c])); }
+  const bool wave_ok = __builtin_amdgcn_ballot_w64(!finite) == 0ull;
+  if (lane == 0u) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { s_box[wave][c] = lo[c]; s_box[wave][3 + c] = hi[c]; }
+    s_box[wave][6] = wave_ok ? 1.0f : 0.0f;
+  }
+  __syncthreads();
+  FocalBounds bb;
+  bb.ok = true; bb.any = count_px != 0u;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { bb.lo[c] = FLT_MAX; bb.hi[c] = -FLT_MAX; }
+  for (uint32_t v = 0; v < 4u; ++v) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      bb.lo[c] = fminf(bb.lo[c], s_box[v][c]);
+      bb.hi[c] = fmaxf(bb.hi[c], s_box[v][3 + c]);
+    }
+    bb.ok = bb.ok && (s_box[v][6] != 0.0f);
+  }
+  const TileFamily fam = make_family(p, bb);
+  uint32_t* const out = p.macro_lists + (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * (p.macro_cap + 1u);
+  const uint32_t n = p.n_tris;
+  uint32_t total = 0, step = 0;
+  bool overflow = false;
+  for (uint32_t base = 0; base < n; base += 256u, ++step) {
+    const uint32_t tri = base + threadIdx.x;
+    const bool valid = tri < n;
+    const uint32_t ti = valid ? tri : (n - 1u);
+    const float4 A0 = p.tri_a[2u * ti], A1 = p.tri_a[2u * ti + 1u];
+    const float bz = p.tri_b[ti];
+    bool keep = valid;
+    if (fam.usable)
+      keep = valid && !tile_misses_triangle(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z});
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+    uint32_t* const slot = s_cnt[step & 1u];                     // double-buffered: one barrier per step
+    if (lane == 0u) slot[wave] = static_cast<uint32_t>(__builtin_popcountll(m));
+    __syncthreads();
+    const uint32_t c0 = slot[0], c1 = slot[1], c2 = slot[2], c3 = slot[3];
+    const uint32_t before = (wave > 0u ? c0 : 0u) + (wave > 1u ? c1 : 0u) + (wave > 2u ? c2 : 0u);
+    const uint32_t step_total = c0 + c1 + c2 + c3;
+    if (total + step_total > p.macro_cap) { overflow = true; break; }   // block-uniform
+    const uint32_t pos = total + before + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+    if (keep) out[1u + pos] = tri;                                // ascending order across waves and steps
+    total += step_total;
+  }
+  if (threadIdx.x == 0u) out[0] = overflow ? 0xFFFFFFFFu : total;
+}
+
+// ------------------------------------------------------------------------------------
 template <bool FMA, int K, bool FILTER, bool STATS, bool BIN, bool ONEPASS>
 __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) void trace_kernel(const TraceParams p) {
   using M = Math<FMA>;
@@ -481,6 +566,17 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   float* const bbox = reinterpret_cast<float*>(bcnt + 8);                                   // 4 waves x (lo[3], hi[3], ok, any)
   uint32_t src_count = n;           // triangles the wave-level classification walks over
   bool src_is_block_list = false;
+  // macro level: this block's macro tile already excludes most of the scene (macro_bin_kernel)
+  const uint32_t* mI = nullptr;     // ascending triangle indices of the macro tile, or null = whole scene
+  if constexpr (BIN && !ONEPASS) {
+    if (p.macro_lists != nullptr) {
+      const uint32_t mt = (blockIdx.y * 8u / p.macro_h) * p.macro_nx + (blockIdx.x * 32u / p.macro_w);
+      const uint32_t* const ml = p.macro_lists + static_cast<size_t>(mt) * (p.macro_cap + 1u);
+      const uint32_t mc = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ml[0])));
+      if (mc != 0xFFFFFFFFu) { mI = ml + 1; src_count = mc; }
+    }
+  }
+  const uint32_t n_src = src_count;  // triangles the block-level pre-cull walks over
   if constexpr (BIN) {
     tl_mark(8);                                                    // loads issued, pinhole + focal point done
     const FocalBounds wb = focal_bounds(focal, inside);
@@ -513,10 +609,12 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
         uint32_t total = 0;
         bool overflow = false;
         uint32_t step = 0;
-        for (uint32_t base = 0; base < n; base += 256u, ++step) {
-          const uint32_t tri = base + threadIdx.x;
-          const bool valid = tri < n;
-          const uint32_t ti = valid ? tri : (n - 1u);
+        for (uint32_t base = 0; base < n_src; base += 256u, ++step) {
+          const uint32_t e = base + threadIdx.x;
+          const bool valid = e < n_src;
+          const uint32_t ei = valid ? e : (n_src - 1u);
+          const uint32_t tri = mI != nullptr ? mI[ei] : ei;
+          const uint32_t ti = tri;
           const float4 A0 = p.tri_a[2u * ti], A1 = p.tri_a[2u * ti + 1u];
           const float bz = p.tri_b[ti];
           bool keep = valid;
@@ -548,7 +646,7 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
       const uint32_t e = base + lane;
       const bool valid = e < src_count;
       const uint32_t ei = valid ? e : (src_count - 1u);
-      const uint32_t tri = src_is_block_list ? bI[ei] : ei;
+      const uint32_t tri = src_is_block_list ? bI[ei] : (mI != nullptr ? mI[ei] : ei);
       const uint32_t ti = tri;
       float4 A0, A1;
       float bz;

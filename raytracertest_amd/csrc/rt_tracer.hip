@@ -275,6 +275,7 @@ struct rt_tracer {
     EventPair e = take_events();
     e.launches = 1;
     HIP_CHECK(hipEventRecord(e.a, stream));
+    attach_macro_lists(p);                                               // part of the launch: timed with it
     HIP_CHECK(rtk::launch_trace(p, fma, filter, bin, K, stream));
     HIP_CHECK(hipEventRecord(e.b, stream));
     hipEvent_t wait_for = nullptr;
@@ -364,6 +365,40 @@ struct rt_tracer {
       list_key = k;
       list_key_valid = true;
     }
+  }
+
+  // Macro level of the classification (scenes that do not fit the per-wave list): sizes the
+  // lists, points the launch at them and runs macro_bin_kernel on the stream ahead of the trace
+  // launch.  Every launch re-bins (the camera may have changed; the pass costs N x macro tiles tests).
+  uint32_t* d_macro_lists = nullptr;
+  size_t macro_lists_words = 0;
+  bool macro = true;                  // RT_FLAG_NO_MACRO_BINS / RT_MI355X_NO_MACRO=1 turn it off
+  static constexpr uint32_t kMacroW = 128, kMacroH = 64, kMacroCapMax = 65536;
+
+  void attach_macro_lists(rtk::TraceParams& p) {
+    p.macro_lists = nullptr;
+    if (!bin || !macro || p.n_tris <= p.bin_list) return;
+    p.macro_w = kMacroW; p.macro_h = kMacroH;
+    if (const char* ms = getenv("RT_MI355X_MACRO_TILE")) {              // tuning: "WxH", multiples of 32 x 8
+      unsigned w = 0, h = 0;
+      if (sscanf(ms, "%ux%u", &w, &h) == 2 && w >= 32u && h >= 8u && w % 32u == 0u && h % 8u == 0u) { p.macro_w = w; p.macro_h = h; }
+    }
+    p.macro_nx = (p.W + p.macro_w - 1u) / p.macro_w;
+    const uint32_t ny = (p.rows + p.macro_h - 1u) / p.macro_h;
+    p.macro_cap = p.n_tris < kMacroCapMax ? p.n_tris : kMacroCapMax;
+    if (const char* mc = getenv("RT_MI355X_MACRO_CAP")) {               // tests: force the overflow fallback
+      const long v = strtol(mc, nullptr, 10);
+      if (v > 0 && static_cast<uint32_t>(v) < p.macro_cap) p.macro_cap = static_cast<uint32_t>(v);
+    }
+    const size_t words = static_cast<size_t>(p.macro_nx) * ny * (p.macro_cap + 1u);
+    if (words > macro_lists_words) {
+      if (d_macro_lists) (void)hipFree(d_macro_lists);
+      d_macro_lists = nullptr; macro_lists_words = 0;
+      HIP_CHECK(hipMalloc(&d_macro_lists, words * sizeof(uint32_t)));
+      macro_lists_words = words;
+    }
+    p.macro_lists = d_macro_lists;
+    HIP_CHECK(rtk::launch_macro_bin(p, fma, stream));
   }
 
   static constexpr int kWindow = 4;
@@ -538,6 +573,10 @@ int rt_tracer_create_ex(const uint32_t imageSize[2], const float cameraPosition[
   t->bin = (opt.flags & RT_FLAG_NO_BINNING) == 0;
   t->nearest_hit = (opt.flags & RT_FLAG_NEAREST_HIT) != 0;
   t->smooth_normals = (opt.flags & RT_FLAG_SMOOTH_NORMALS) != 0;
+  {
+    const char* nm = getenv("RT_MI355X_NO_MACRO");
+    t->macro = (opt.flags & RT_FLAG_NO_MACRO_BINS) == 0 && !(nm && nm[0] == '1');
+  }
   t->k_req = opt.samples_in_flight;
   t->chunk_req = opt.lds_chunk;
   t->bin_list_req = opt.bin_list;
@@ -582,6 +621,7 @@ void rt_tracer_destroy(rt_tracer* t) {                                   // RayT
   t->drain_events();
   for (EventPair& e : t->free_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (t->d_tile_lists) (void)hipFree(t->d_tile_lists);
+  if (t->d_macro_lists) (void)hipFree(t->d_macro_lists);
   if (t->d_tri_n) (void)hipFree(t->d_tri_n);
   if (t->d_tri) (void)hipFree(t->d_tri);
   if (t->d_tri_b) (void)hipFree(t->d_tri_b);
@@ -789,6 +829,7 @@ int rt_tracer_trace_stats(rt_tracer* t, uint32_t samples, uint64_t out[16]) {
     rtk::TraceParams p = t->params(samples);
     p.stats = counters.as<unsigned long long>();
     p.flags = t->nearest_hit ? rtk::TRACE_NEAREST_HIT : 0u;
+    t->attach_macro_lists(p);
     HIP_CHECK(rtk::launch_trace(p, t->fma, t->filter, t->bin, t->pick_k(samples), t->stream));
     HIP_CHECK(hipStreamSynchronize(t->stream));
     HIP_CHECK(hipMemcpy(out, counters.p, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
@@ -933,6 +974,7 @@ extern "C" int rt_dbg_trace_timeline(rt_tracer* t, uint32_t samples, unsigned lo
     p.flags = rtk::TRACE_ZERO_ACC | rtk::TRACE_EMIT_IMAGE | (t->nearest_hit ? rtk::TRACE_NEAREST_HIT : 0u);
     p.image = t->d_image;
     p.timeline = buf.as<unsigned long long>();
+    t->attach_macro_lists(p);
     HIP_CHECK(rtk::launch_trace(p, t->fma, t->filter, t->bin, t->pick_k(samples), t->stream));
     HIP_CHECK(hipStreamSynchronize(t->stream));
     HIP_CHECK(hipMemcpy(out, buf.p, words * sizeof(unsigned long long), hipMemcpyDeviceToHost));

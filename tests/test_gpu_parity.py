@@ -373,6 +373,27 @@ def test_binning_equals_full_scan_cameras(rt, cam):
     _bin_pair(40, 24, scene("cornell"), 2, 3, **cam)
 
 
+def test_macro_level_on_off_and_overflow_fallback(rt, monkeypatch):
+    """Large scenes: macro-tile lists on (default) = off = full scan; a macro list that overflows its
+    capacity falls back to scanning the scene for that macro tile."""
+    import raytracertest_amd as R
+    from raytracertest_amd import scenes
+    scn = scenes.random_triangles(6000, 31)
+    def run(**kw):
+        g = R.RayTracer((200, 136), (0, 0, 0), (0.1, -0.05), 70.0, 3.0, 0.05, seed=8, **kw)
+        assert g.UploadScene(scn)
+        g.Trace(2, 5, 0); assert g.Wait()
+        return g.RenderBuffer().view(np.uint32).copy(), g.RngStates().copy()
+    ref = run(no_binning=True)
+    on = run()
+    off = run(no_macro_bins=True)
+    monkeypatch.setenv("RT_MI355X_MACRO_CAP", "40")
+    tiny = run()
+    monkeypatch.delenv("RT_MI355X_MACRO_CAP")
+    for other in (on, off, tiny):
+        assert np.array_equal(ref[0], other[0]) and np.array_equal(ref[1], other[1])
+
+
 def test_binning_with_degenerate_and_nonfinite_triangles(rt):
     from raytracertest_amd import scenes
     scn = scenes.random_triangles(200, 5).copy()
