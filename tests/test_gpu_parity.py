@@ -394,6 +394,20 @@ def test_macro_level_on_off_and_overflow_fallback(rt, monkeypatch):
         assert np.array_equal(ref[0], other[0]) and np.array_equal(ref[1], other[1])
 
 
+def test_large_scene_three_level_classification_equals_full_scan(rt):
+    """60 000 triangles: macro tile -> block -> wave tile lists (with multi-round wave lists) = full scan."""
+    import raytracertest_amd as R
+    from raytracertest_amd import scenes
+    scn = scenes.random_triangles(60000, 4711)
+    out = []
+    for kw in (dict(), dict(no_binning=True)):
+        g = R.RayTracer((160, 96), (0, 0, 0), (0.0, 0.0), 70.0, 3.0, 0.05, seed=3, **kw)
+        assert g.UploadScene(scn)
+        g.Trace(1, 5, 0); assert g.Wait()
+        out.append((g.RenderBuffer().view(np.uint32).copy(), g.RngStates().copy()))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
 def test_binning_with_degenerate_and_nonfinite_triangles(rt):
     from raytracertest_amd import scenes
     scn = scenes.random_triangles(200, 5).copy()
