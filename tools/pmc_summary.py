@@ -11,6 +11,9 @@ for name in ("bench_c3.json", "bench_c4.json", "bench_c3_under_rocprof.json"):
     shutil.copy(os.path.join(src, name), os.path.join(dst, "%s_%s" % (tag, name)))
 stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
 shutil.copy(stats[0], os.path.join(dst, "%s_c3_kernel_stats.csv" % tag))
+stats4 = glob.glob(os.path.join(src, "stats_c4", "*", "*kernel_stats.csv"))
+if stats4:
+    shutil.copy(stats4[0], os.path.join(dst, "%s_c4_kernel_stats.csv" % tag))
 rows = []
 means = {}
 for p in ("pmc_fetch", "pmc_write", "pmc_sq"):
@@ -37,11 +40,24 @@ json.dump({
            "note": "bench launches treat the accumulators as zero (no accumulator read): reads = 24 B/pixel RNG state, writes = 24 B RNG + 16 B RGBA + 4 B count + 4 B BGRA8"}},
     open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
 valu = means[(tk, "SQ_INSTS_VALU")]
+c4 = {}
+f4 = glob.glob(os.path.join(src, "pmc_sq_c4", "*", "*counter_collection.csv"))
+if f4:
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f4[0])):
+        agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    m4 = {k: sum(v) / len(v) for k, v in agg.items()}
+    t4 = [k for (k, c) in m4 if "trace_kernel" in k][0]
+    b4 = [k for (k, c) in m4 if "macro_bin_kernel" in k]
+    v4 = m4[(t4, "SQ_INSTS_VALU")] + (m4[(b4[0], "SQ_INSTS_VALU")] if b4 else 0.0)
+    c4 = {"C4": {"valu_wave_instructions_per_launch": int(v4), "of_which_macro_bin_kernel": int(m4[(b4[0], "SQ_INSTS_VALU")]) if b4 else 0,
+                 "waves": int(m4[(t4, "SQ_WAVES")]), "valu_per_wave": round(m4[(t4, "SQ_INSTS_VALU")] / m4[(t4, "SQ_WAVES")], 1),
+                 "lane_instructions_per_ray": round(v4 * 64 / (3840 * 2160 * 64), 1)}}
 json.dump({
     "_method": "rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE "
                "(%s, own pass). Per-launch means for the C3 trace kernel; wave-level instruction counts (one count per wave64 instruction)." % tag,
     "C3": {"valu_wave_instructions_per_launch": int(valu), "salu": int(means[(tk, "SQ_INSTS_SALU")]), "lds": int(means[(tk, "SQ_INSTS_LDS")]),
            "waves": int(means[(tk, "SQ_WAVES")]), "valu_per_wave": round(valu / means[(tk, "SQ_WAVES")], 1),
-           "lane_instructions_per_ray": round(valu * 64 / (npix * 16), 1)}},
+           "lane_instructions_per_ray": round(valu * 64 / (npix * 16), 1)}, **c4},
     open(os.path.join(dst, "valu_issue.json"), "w"), indent=1)
 print("traffic %d B/launch (algorithmic %d), VALU wave-instructions/launch %d (%.0f per wave)" % (traffic, alg, valu, valu / means[(tk, "SQ_WAVES")]))
