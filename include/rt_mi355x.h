@@ -146,8 +146,10 @@ int  rt_tracer_sync(rt_tracer* t);
  * RayTracerImpl.cu:242-243); emit_image != 0: the BGRA8 image is refreshed too (an update or
  * the last iteration, RayTracerImpl.cu:259-270,287-295).  No callbacks, no host sync. */
 int  rt_tracer_launch(rt_tracer* t, uint32_t samples, int clear_first, int emit_image);
-/* Sum of the trace-kernel durations (HIP events on the tracer's stream) and number of
- * trace-kernel launches since the last reset; reset_after != 0 clears both. */
+/* Sum of the durations of the SAMPLED trace launches (HIP events on the tracer's stream, around
+ * every 4th launch and every launch the caller waits for: an event pair costs ~5 us per launch) and
+ * their number since the last reset; total_ms / launches = mean launch duration.  reset_after != 0
+ * clears both and makes the next launch a sampled one. */
 int  rt_tracer_kernel_time(rt_tracer* t, double* total_ms, uint64_t* launches, int reset_after);
 /* One instrumented launch (clear + trace of `samples` spp with counters; not a timed path).
  * Lane-level counters need RT_FLAG_NO_FILTER (reference-order path), wave-level ones the
