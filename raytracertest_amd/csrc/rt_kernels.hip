@@ -244,10 +244,27 @@ static void launch_trace_f(const TraceParams& p, bool filter, bool bin, int K, d
   else launch_trace_b<FMA, false, STATS>(p, bin, K, grid, lds, st);
 }
 
+template <bool FMA>
+static void launch_trace_fused(const TraceParams& p, int K, dim3 grid, size_t lds, hipStream_t st) {
+  const bool onepass = p.n_tris <= p.bin_list;
+#define RT_FUSED(KK, OP) hipLaunchKernelGGL((trace_kernel<FMA, KK, true, false, true, OP, true>), grid, dim3(256), lds, st, p)
+  if (onepass) { if (K == 1) RT_FUSED(1, true); else if (K == 2) RT_FUSED(2, true); else RT_FUSED(4, true); }
+  else { if (K == 1) RT_FUSED(1, false); else if (K == 2) RT_FUSED(2, false); else RT_FUSED(4, false); }
+#undef RT_FUSED
+}
+
+bool trace_can_fuse(bool filter, bool bin) { return filter && bin; }
+
 hipError_t launch_trace(const TraceParams& p, bool fma, bool filter, bool bin, int K, hipStream_t st) {
   if (p.rows == 0 || p.W == 0 || p.samples == 0) return hipSuccess;
   const dim3 grid(cdiv(p.W, 32), cdiv(p.rows, 8));
   const size_t lds = trace_lds_bytes(p, bin);
+  if (p.iters > 1u) {                // fused iterations: default (filtered, classified, un-instrumented) kernels only
+    if (!trace_can_fuse(filter, bin) || p.stats != nullptr) return hipErrorInvalidValue;
+    if (fma) launch_trace_fused<true>(p, K, grid, lds, st);
+    else launch_trace_fused<false>(p, K, grid, lds, st);
+    return hipGetLastError();
+  }
   if (p.stats != nullptr) {          // instrumented build of the same kernel (not the timed path)
     if (fma) launch_trace_f<true, true>(p, filter, bin, K, grid, lds, st);
     else launch_trace_f<false, true>(p, filter, bin, K, grid, lds, st);

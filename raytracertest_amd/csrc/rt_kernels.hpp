@@ -33,6 +33,7 @@ struct TraceParams {
 #ifdef RT_TIMELINE
   unsigned long long* timeline;   // experiment builds only (tools/timeline.py): 8 u64 per wave
 #endif
+  uint32_t  iters;          // fused launches: consecutive iterations of p.samples samples (>= 1)
   // Macro-tile triangle lists (scenes larger than the per-wave list): written by macro_bin_kernel
   // once per launch, read by the trace kernel's block-level pre-cull instead of the whole scene.
   // Per macro tile of macro_w x macro_h pixels: count (or 0xFFFFFFFF = overflow, scan the scene)
@@ -69,6 +70,7 @@ hipError_t launch_convert(const float4* render, const uint32_t* counts, uint32_t
 
 hipError_t launch_dbg_hit_triangle(bool fma, uint32_t n, const float* rays, const float* tris, int eps_mode,
                                    int* hit, float* tuv, float* normal, float* point, hipStream_t st);
+bool trace_can_fuse(bool filter, bool bin);      // launches with TraceParams::iters > 1 are available
 hipError_t launch_macro_bin(const TraceParams& p, bool fma, hipStream_t st);
 hipError_t launch_dbg_check_midrange(unsigned long long* out, hipStream_t st);
 hipError_t launch_dbg_valu_peak(uint32_t blocks, int iters, float* out, unsigned long long* clk, hipStream_t st);

@@ -481,8 +481,12 @@ __global__ __launch_bounds__(256) void macro_bin_kernel(TraceParams p) {
 }
 
 // ------------------------------------------------------------------------------------
-template <bool FMA, int K, bool FILTER, bool STATS, bool BIN, bool ONEPASS>
-__global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) void trace_kernel(const TraceParams p) {
+// FUSE: the launch runs p.iters consecutive iterations of the host loop (RayTracerImpl.cu:246-249)
+// of p.samples samples each: the per-iteration `render += accu` (:141-143) keeps its order of
+// additions, so the buffers end bit-identical to p.iters separate launches -- without their
+// state traffic, tile family and classification.  Used between two update points of a Trace.
+template <bool FMA, int K, bool FILTER, bool STATS, bool BIN, bool ONEPASS, bool FUSE = false>
+__global__ __launch_bounds__(256, (ONEPASS && K == 2 && !FUSE) ? 5 : RT_TRACE_WAVES(K)) void trace_kernel(const TraceParams p) {
   using M = Math<FMA>;
   extern __shared__ float4 s_mem[];
 
@@ -709,6 +713,11 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
     list_complete = true;
   }
   tl_mark(1);                                                      // family + classification done
+  const uint32_t iters = FUSE ? p.iters : 1u;
+  float rx = 0.0f, ry = 0.0f, rz = 0.0f, rw = 0.0f;                // FUSE: the pixel's RenderBuffer value so far
+  uint32_t cnt_first = 0u;
+  for (uint32_t it = 0; it < iters; ++it) {                        // FUSE: the host loop's iterations, :246
+  if constexpr (FUSE) { ax = 0.0f; ay = 0.0f; az = 0.0f; }          // accu, :133
   for (uint32_t s0 = 0; s0 < p.samples; s0 += K) {                 // :134, K samples per pass
     if (s0 == static_cast<uint32_t>(K)) tl_mark(2);                // first batch done (includes the wait for the RNG state)
     V3 o[K], d[K];
@@ -827,6 +836,15 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
     }
   }
 
+  if constexpr (FUSE) {                                            // end of iteration `it`: :140-143
+    if (it == 0u && !(p.flags & TRACE_ZERO_ACC) && inside) {        // wave-uniform but for `inside`
+      const float4 r0 = p.render[pix];
+      rx = r0.x; ry = r0.y; rz = r0.z; rw = r0.w;
+      cnt_first = p.counts[pix];
+    }
+    rx += ax; ry += ay; rz += az;
+  }
+  }                                                                // iterations
   tl_mark(3);                                                      // all samples done
   if (inside) {
     // Accumulators are read here, not prefetched at kernel start: five registers held across
@@ -834,14 +852,20 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
     // read latency of a finished wave (measured C3 169.4 -> 164.9 us, progressive launches equal).
     float4 acc_in = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     uint32_t cnt_in = 0u;
-    if (!(p.flags & TRACE_ZERO_ACC)) {                              // wave-uniform
-      acc_in = p.render[pix];
-      cnt_in = p.counts[pix];
+    if constexpr (!FUSE) {
+      if (!(p.flags & TRACE_ZERO_ACC)) {                            // wave-uniform
+        acc_in = p.render[pix];
+        cnt_in = p.counts[pix];
+      }
     }
-    const uint32_t cnt = cnt_in + p.samples;                        // :140
+    const uint32_t cnt = FUSE ? cnt_first + iters * p.samples : cnt_in + p.samples;   // :140
     p.counts[pix] = cnt;
     float4 acc = acc_in;
-    acc.x += ax; acc.y += ay; acc.z += az;                          // :141-143, alpha untouched (:144)
+    if constexpr (FUSE) {
+      acc = make_float4(rx, ry, rz, rw);
+    } else {
+      acc.x += ax; acc.y += ay; acc.z += az;                        // :141-143, alpha untouched (:144)
+    }
     p.render[pix] = acc;
     if (p.flags & TRACE_EMIT_IMAGE) {                               // fused rt::ConverterKernel, :164-168
       const float c = static_cast<float>(cnt);

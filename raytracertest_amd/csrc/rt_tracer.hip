@@ -264,9 +264,10 @@ struct rt_tracer {
   // memset, no accumulator read), a launch whose result is handed out also writes BGRA8.
   // sync_after: 0 = none, 1 = wait for this launch (the reference's behaviour, :228),
   // N > 1 = keep at most N launches in flight (wait for the launch N-1 back).
-  void enqueue_trace_launch(uint32_t samples, uint32_t flags, int sync_after) {
+  void enqueue_trace_launch(uint32_t samples, uint32_t flags, int sync_after, uint32_t iters = 1) {
     const int K = pick_k(samples);
     rtk::TraceParams p = params(samples);
+    p.iters = iters;
     p.flags = flags | (nearest_hit ? rtk::TRACE_NEAREST_HIT : 0u);
     p.image = d_image;
     attach_tile_lists(p, (flags & rtk::TRACE_ZERO_ACC) != 0u);
@@ -422,25 +423,43 @@ struct rt_tracer {
   static constexpr int kWindow = 4;
 
   // RayTracerImpl::TraceFunct, RayTracerImpl.cu:236-315 (runs on the render thread)
+  // How many consecutive iterations one launch may run (1 = no fusing): bounded so that a launch
+  // stays short (<= 64 samples per pixel) and a Stop() takes effect within a few launches.
+  uint32_t fused_iterations(uint32_t samplesPerIteration) const {
+    static const bool off = [] { const char* e = getenv("RT_MI355X_NO_FUSE"); return e && e[0] == '1'; }();
+    if (off || !rtk::trace_can_fuse(filter, bin) || samplesPerIteration == 0u) return 1u;
+    const uint32_t n = 64u / samplesPerIteration;
+    return n < 1u ? 1u : n;
+  }
+
   void trace_funct(uint32_t iterationCount, uint32_t samplesPerIteration, uint32_t updateInterval) {
     try {
       use_device();
       bool cleared = false;                                              // :242-243, fused into launch 0
-      for (uint32_t i = 0; !stopped && i < iterationCount; ++i) {         // :246
+      uint32_t i = 0;
+      while (!stopped && i < iterationCount) {                           // :246
         rt_callback_fn cb; void* user;
         { std::lock_guard<std::mutex> lk(state_mu); cb = update_cb; user = update_user; }
-        const bool update = cb != nullptr && i > 0 && updateInterval > 0 && i % updateInterval == 0;   // :256
+        auto is_update = [&](uint32_t k) { return cb != nullptr && k > 0 && updateInterval > 0 && k % updateInterval == 0; };   // :256
+        // Iterations nobody observes in between -- up to the next update point or the end of the
+        // Trace -- run as ONE launch (fused_iterations(): bit-identical to separate launches).
+        const uint32_t last_allowed = iterationCount - 1u - i < fused_iterations(samplesPerIteration) - 1u
+                                          ? iterationCount - 1u : i + fused_iterations(samplesPerIteration) - 1u;
+        uint32_t e = i;                                                  // last iteration of this launch
+        while (e < last_allowed && !is_update(e)) ++e;
+        const bool update = is_update(e);
         const uint32_t flags = (cleared ? 0u : rtk::TRACE_ZERO_ACC) |
-                               ((update || i + 1 == iterationCount) ? rtk::TRACE_EMIT_IMAGE : 0u);
+                               ((update || e + 1 == iterationCount) ? rtk::TRACE_EMIT_IMAGE : 0u);
         // The reference blocks on every launch (:228), which makes a stop take effect after one
         // kernel.  Here up to `kWindow` launches are in flight: the host never starves the GPU on
-        // short launches, and a stop still takes effect within kWindow kernels.
-        enqueue_trace_launch(samplesPerIteration, flags, update ? 1 : kWindow);          // :249
+        // short launches, and a stop still takes effect within a few launches.
+        enqueue_trace_launch(samplesPerIteration, flags, update ? 1 : kWindow, e - i + 1u);   // :249
         cleared = true;
         if (update) {
           fetch_image();                                                 // :259-270 (conversion fused)
           cb(h_image, static_cast<size_t>(npix()) * sizeof(uint32_t), user);              // :272
         }
+        i = e + 1u;
       }
       drain_events();
       if (!cleared) {                                                    // no launch ran: plain clear (+ convert below)
@@ -817,11 +836,15 @@ int rt_tracer_trace_enqueue(rt_tracer* t, uint32_t iterationCount, uint32_t samp
       t->clear_accumulators();
       t->convert();
     }
-    for (uint32_t i = 0; i < iterationCount; ++i)
+    const uint32_t group = t->fused_iterations(samplesPerIteration);
+    for (uint32_t i = 0; i < iterationCount;) {
+      const uint32_t n = iterationCount - i < group ? iterationCount - i : group;
       t->enqueue_trace_launch(samplesPerIteration,
                               (i == 0 ? rtk::TRACE_ZERO_ACC : 0u) |
-                                  (i + 1 == iterationCount ? rtk::TRACE_EMIT_IMAGE : 0u),
-                              0);
+                                  (i + n == iterationCount ? rtk::TRACE_EMIT_IMAGE : 0u),
+                              0, n);
+      i += n;
+    }
   });
 }
 

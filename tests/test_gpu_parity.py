@@ -303,6 +303,35 @@ def test_candidate_lists_reused_across_iterations_follow_camera_and_scene_change
     g.Trace(3, 2, 0); assert g.Wait(); o.trace(3, 2); assert_frame_equal(g, o)
 
 
+@pytest.mark.parametrize("name,n_it,spp", [("cornell", 9, 2), ("rand300", 5, 3), ("demo3", 70, 1)])
+def test_fused_iterations_equal_separate_launches(rt, orc, name, n_it, spp):
+    """Iterations nobody observes run as one launch: same bits as one launch per iteration
+    (rt_tracer_launch), as the oracle's loop, and with the update cadence unchanged."""
+    import raytracertest_amd as R
+    W, H = 50, 30
+    scn = scene(name)
+    a = R.RayTracer((W, H), (0, 0, 0), (0.0, 0.0), 70.0, 3.0, 0.05, seed=12)
+    b = R.RayTracer((W, H), (0, 0, 0), (0.0, 0.0), 70.0, 3.0, 0.05, seed=12)
+    c = R.RayTracer((W, H), (0, 0, 0), (0.0, 0.0), 70.0, 3.0, 0.05, seed=12)
+    o = orc.OracleTracer(W, H, (0.0, 0.0), 70.0, 3.0, 0.05, seed=12, nthreads=8)
+    for g in (a, b, c):
+        assert g.UploadScene(scn)
+    o.upload_scene(scn)
+    a.TraceEnqueue(n_it, spp); a.Sync()                      # fused groups
+    for i in range(n_it):                                    # one launch per iteration
+        b.Launch(spp, clear_first=(i == 0), emit_image=(i + 1 == n_it))
+    b.Sync()
+    updates = []
+    c.SetUpdateCallback(lambda img, size: updates.append(img.copy()))
+    c.Trace(n_it, spp, 4); assert c.Wait()                   # fused between update points
+    o.trace(n_it, spp)
+    for g in (a, b, c):
+        assert np.array_equal(u32(g.RenderBuffer()), u32(o.render))
+        assert np.array_equal(g.SampleCounts(), o.counts) and np.array_equal(g.RngStates(), o.rng)
+        assert np.array_equal(g.Image(), o.image)
+    assert len(updates) == (n_it - 1) // 4
+
+
 def test_trace_enqueue_matches_trace(rt, orc):
     g, o = run_pair(rt, orc, 48, 28, scene("rand300"), 2, 4)
     import raytracertest_amd as R
