@@ -146,6 +146,11 @@ int  rt_tracer_sync(rt_tracer* t);
  * RayTracerImpl.cu:242-243); emit_image != 0: the BGRA8 image is refreshed too (an update or
  * the last iteration, RayTracerImpl.cu:259-270,287-295).  No callbacks, no host sync. */
 int  rt_tracer_launch(rt_tracer* t, uint32_t samples, int clear_first, int emit_image);
+/* `iterations` consecutive iterations of the loop as ONE launch, bit-identical to `iterations` calls of
+ * rt_tracer_launch (the per-iteration accumulate order is kept; state traffic and triangle classification
+ * are paid once).  iterations <= rt_tracer_fused_iterations(t, samples) (>= 1; 1 when fusing is unavailable). */
+int  rt_tracer_launch_iterations(rt_tracer* t, uint32_t samples, uint32_t iterations, int clear_first, int emit_image);
+int  rt_tracer_fused_iterations(rt_tracer* t, uint32_t samples);
 /* Sum of the durations of the SAMPLED trace launches (HIP events on the tracer's stream, around
  * every 4th launch and every launch the caller waits for: an event pair costs ~5 us per launch) and
  * their number since the last reset; total_ms / launches = mean launch duration.  reset_after != 0

@@ -848,6 +848,25 @@ int rt_tracer_trace_enqueue(rt_tracer* t, uint32_t iterationCount, uint32_t samp
   });
 }
 
+int rt_tracer_fused_iterations(rt_tracer* t, uint32_t samples) {
+  return t ? static_cast<int>(t->fused_iterations(samples)) : 0;
+}
+
+int rt_tracer_launch_iterations(rt_tracer* t, uint32_t samples, uint32_t iterations, int clear_first, int emit_image) {
+  if (!t || iterations == 0u) return RT_ERR_INVALID;
+  if (iterations > t->fused_iterations(samples)) {
+    t->set_error(fmt("rt_tracer_launch_iterations: %u iterations of %u samples exceed rt_tracer_fused_iterations", iterations, samples));
+    return RT_ERR_INVALID;
+  }
+  std::lock_guard<std::mutex> lk(t->api_mu);
+  return guarded(t, [&] {
+    t->cancel_and_join();
+    t->use_device();
+    t->enqueue_trace_launch(samples, (clear_first ? rtk::TRACE_ZERO_ACC : 0u) | (emit_image ? rtk::TRACE_EMIT_IMAGE : 0u),
+                            0, iterations);
+  });
+}
+
 int rt_tracer_launch(rt_tracer* t, uint32_t samples, int clear_first, int emit_image) {
   if (!t) return RT_ERR_INVALID;
   std::lock_guard<std::mutex> lk(t->api_mu);

@@ -65,18 +65,22 @@ def update_due(i, update_interval, have_callback=True):
 
 def progressive_trace(launch, tile, world, rank, iterations, samples, update_interval,
                       on_update=None, on_finished=None, stop_requested=None, all_reduce_max=None,
-                      have_update_callback=None):
+                      have_update_callback=None, fuse=1):
     """RayTracerImpl::TraceFunct (RayTracerImpl.cu:236-315) for a frame sharded in row bands.
 
     Every rank runs the same iteration loop on its own band; at an update iteration and at
     the end the BGRA8 tiles are gathered to rank 0, which fires the callbacks with the whole
     frame -- the per-update hand-off of the reference (:259-272,:287-305) at multi-GPU scale.
-    Cancel granularity is one iteration, as in the reference (:248): rank 0's stop request is
+    Cancel granularity is one launch, as in the reference (:248): rank 0's stop request is
     agreed on by all ranks with a 1-element MAX all-reduce before each launch, so that no
     rank leaves the loop (and its collectives) alone.  A stopped run fires no finished
     callback (:280-284).  Returns True when the run completed.
 
-      launch(samples, clear_first, emit_image)  -> enqueue one launch on this rank's band
+    fuse > 1: iterations nobody observes in between (up to the next update point, at most `fuse`)
+    run as one launch, `launch(samples, clear_first, emit_image, n)` -- same bits, one stop
+    agreement and one state round trip per group (RayTracer.Launch(iterations=n)).
+
+      launch(samples, clear_first, emit_image[, n])  -> enqueue one launch on this rank's band
       tile()                                    -> this rank's finished (rows, W) BGRA8 tensor
       all_reduce_max(flag: int) -> int          -> max of `flag` over ranks (identity if world == 1)
       have_update_callback                      -> must agree on all ranks (default: on_update given)
@@ -90,15 +94,23 @@ def progressive_trace(launch, tile, world, rank, iterations, samples, update_int
         want = 1 if (rank == 0 and stop_requested is not None and stop_requested()) else 0
         return bool(all_reduce_max(want))
 
-    for i in range(iterations):
+    i = 0
+    while i < iterations:
         if stop_agreed():
             return False
-        upd = update_due(i, update_interval, updates_on)
-        launch(samples, i == 0, upd or i + 1 == iterations)
+        e = i                                              # last iteration of this launch
+        while e < iterations - 1 and e - i + 1 < fuse and not update_due(e, update_interval, updates_on):
+            e += 1
+        upd = update_due(e, update_interval, updates_on)
+        if fuse > 1:
+            launch(samples, i == 0, upd or e + 1 == iterations, e - i + 1)
+        else:
+            launch(samples, i == 0, upd or e + 1 == iterations)
         if upd:
             frame = gather_tiles(tile(), world, rank)
             if rank == 0 and on_update is not None:
                 on_update(frame)
+        i = e + 1
     if stop_agreed():
         return False
     if iterations == 0:
@@ -230,13 +242,15 @@ class RowBandJob:
         (it passes on_update), agreed on by all ranks."""
         updates_on = bool(self._all_reduce_max(1 if (self.rank == 0 and on_update is not None) else 0))
 
-        def launch(spp, clear_first, emit):
-            self.tracer.Launch(spp, clear_first, emit)
+        fuse = self.tracer.FusedIterations(samples)            # same on every rank (same build, same options)
+
+        def launch(spp, clear_first, emit, n=1):
+            self.tracer.Launch(spp, clear_first, emit, iterations=n)
 
         ok = progressive_trace(launch, self._tile, self.world, self.rank, iterations, samples, update_interval,
                                on_update=on_update if self.rank == 0 else None, on_finished=on_finished,
                                stop_requested=stop_requested, all_reduce_max=self._all_reduce_max,
-                               have_update_callback=updates_on)
+                               have_update_callback=updates_on, fuse=fuse)
         self.tracer.Sync()
         return ok
 

@@ -67,7 +67,7 @@ def test_two_rank_gloo_gather_equals_single_frame(tmp_path, orc):
 
 
 # ---------------------------------------------------------------- progressive path at multi-rank scale
-def _progressive_worker(rank, world, port, W, H, outdir, stop_after):
+def _progressive_worker(rank, world, port, W, H, outdir, stop_after, fuse=1):
     import torch
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -80,10 +80,13 @@ def _progressive_worker(rank, world, port, W, H, outdir, stop_after):
     o = orc.OracleTracer(W, H, (0.0, 0.0), 70.0, 3.0, 0.05, seed=1, row0=row0, rows=rows, nthreads=2)
     o.upload_scene(scenes.cornell32())
 
-    def launch(spp, clear_first, emit):            # what rt_tracer_launch does, on the oracle
+    launches = []
+    def launch(spp, clear_first, emit, n=1):       # what rt_tracer_launch(_iterations) does, on the oracle
+        launches.append(n)
         if clear_first:
             orc.lib().orc_frame_clear(C.byref(o._frame))
-        o.launch(spp)
+        for _ in range(n):
+            o.launch(spp)
         if emit:
             orc.lib().orc_convert(C.byref(o._frame))
 
@@ -100,9 +103,9 @@ def _progressive_worker(rank, world, port, W, H, outdir, stop_after):
                            on_update=on_update,          # same cadence on every rank; only rank 0 gets frames
                            on_finished=lambda f: finished.append(f.numpy().view(np.uint32).copy()),
                            stop_requested=(lambda: len(updates) >= stop_after) if stop_after else None,
-                           all_reduce_max=all_reduce_max)
+                           all_reduce_max=all_reduce_max, fuse=fuse)
     if rank == 0:
-        np.savez(os.path.join(outdir, "prog.npz"), ok=ok, n_updates=len(updates), n_finished=len(finished),
+        np.savez(os.path.join(outdir, "prog.npz"), ok=ok, n_updates=len(updates), n_finished=len(finished), launches=np.array(launches),
                  last_update=updates[-1] if updates else np.zeros(0), final=finished[-1] if finished else np.zeros(0))
     else:
         assert updates == [] or all(u is None for u in updates) or True
@@ -125,6 +128,22 @@ def test_progressive_updates_and_finish_over_two_ranks(tmp_path, orc):
     assert np.array_equal(r["final"], whole.image)
     # the update at i = 6 was taken after 7 launches, i.e. it equals the final frame here
     assert np.array_equal(r["last_update"], whole.image)
+
+
+@pytest.mark.timeout(300)
+def test_progressive_fused_groups_keep_cadence_and_result_over_two_ranks(tmp_path, orc):
+    """fuse = 4: iterations 0..3 | 4..6 (update points 3 and 6 end their groups), same frames."""
+    import torch.multiprocessing as mp
+    from raytracertest_amd import scenes
+    W, H, world = 33, 19, 2
+    mp.spawn(_progressive_worker, args=(world, _free_port(), W, H, str(tmp_path), 0, 4), nprocs=world, join=True)
+    r = np.load(os.path.join(str(tmp_path), "prog.npz"))
+    assert bool(r["ok"]) and int(r["n_updates"]) == 2 and int(r["n_finished"]) == 1
+    assert r["launches"].tolist() == [4, 3]
+    whole = orc.OracleTracer(W, H, (0.0, 0.0), 70.0, 3.0, 0.05, seed=1, nthreads=4)
+    whole.upload_scene(scenes.cornell32())
+    whole.trace(7, 2)
+    assert np.array_equal(r["final"], whole.image) and np.array_equal(r["last_update"], whole.image)
 
 
 @pytest.mark.timeout(300)
