@@ -33,6 +33,7 @@ struct TraceParams {
 #ifdef RT_TIMELINE
   unsigned long long* timeline;   // experiment builds only (tools/timeline.py): 8 u64 per wave
 #endif
+  uint32_t* image_host;     // optional second BGRA8 target in pinned host memory (update hand-off), or null
   uint32_t  iters;          // fused launches: consecutive iterations of p.samples samples (>= 1)
   // Macro-tile triangle lists (scenes larger than the per-wave list): written by macro_bin_kernel
   // once per launch, read by the trace kernel's block-level pre-cull instead of the whole scene.

@@ -869,7 +869,11 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2 && !FUSE) ? 5 : RT_TRACE_WA
     p.render[pix] = acc;
     if (p.flags & TRACE_EMIT_IMAGE) {                               // fused rt::ConverterKernel, :164-168
       const float c = static_cast<float>(cnt);
-      p.image[pix] = rtd::pack_color(255.0f * (acc.x / c), 255.0f * (acc.y / c), 255.0f * (acc.z / c));
+      const uint32_t bgra = rtd::pack_color(255.0f * (acc.x / c), 255.0f * (acc.y / c), 255.0f * (acc.z / c));
+      p.image[pix] = bgra;
+      // update hand-off: the same value straight into the caller-visible pinned host image (posted
+      // PCIe writes, one 256-byte row segment per wave store) -- no device-to-host copy afterwards
+      if (p.image_host != nullptr) p.image_host[pix] = bgra;
     }
     p.rng[0 * static_cast<size_t>(p.npix) + pix] = rng.d;           // :146
     p.rng[1 * static_cast<size_t>(p.npix) + pix] = rng.v0;

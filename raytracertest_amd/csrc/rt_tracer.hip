@@ -132,6 +132,9 @@ struct rt_tracer {
   uint32_t* d_image = nullptr;
   uint32_t* d_rng = nullptr;
   uint32_t* h_image = nullptr;      // pinned, handed to callbacks
+  uint32_t* h_image_alt = nullptr;  // second pinned image: update i+1 is produced while the callback reads update i
+  hipEvent_t handoff_event = nullptr;
+  int handoff_next = 0;             // which of the two host images the next emitting launch of a Trace writes
   float4* d_tri = nullptr;          // (e2.xyz,e1.x),(e1.yz,v0.xy) records
   float* d_tri_b = nullptr;         // v0.z
   float4* d_tri_color = nullptr;
@@ -183,6 +186,8 @@ struct rt_tracer {
     if (d_image) (void)hipFree(d_image);
     if (d_rng) (void)hipFree(d_rng);
     if (h_image) (void)hipHostFree(h_image);
+    if (h_image_alt) (void)hipHostFree(h_image_alt);
+    h_image_alt = nullptr;
     d_render = nullptr; d_counts = nullptr; d_image = nullptr; d_rng = nullptr; h_image = nullptr;
   }
 
@@ -201,6 +206,9 @@ struct rt_tracer {
     HIP_CHECK(hipMalloc(&d_counts, n * sizeof(uint32_t)));
     HIP_CHECK(hipMalloc(&d_image, n * sizeof(uint32_t)));
     HIP_CHECK(hipHostMalloc(&h_image, n * sizeof(uint32_t), hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc(&h_image_alt, n * sizeof(uint32_t), hipHostMallocDefault));
+    memset(h_image, 0, n * sizeof(uint32_t));
+    memset(h_image_alt, 0, n * sizeof(uint32_t));
     // the reference leaves new buffers uninitialised until the first Trace clears them; we
     // zero them so that reading before a Trace is defined
     HIP_CHECK(hipMemsetAsync(d_render, 0, n * sizeof(float4), stream));
@@ -264,10 +272,12 @@ struct rt_tracer {
   // memset, no accumulator read), a launch whose result is handed out also writes BGRA8.
   // sync_after: 0 = none, 1 = wait for this launch (the reference's behaviour, :228),
   // N > 1 = keep at most N launches in flight (wait for the launch N-1 back).
-  void enqueue_trace_launch(uint32_t samples, uint32_t flags, int sync_after, uint32_t iters = 1) {
+  void enqueue_trace_launch(uint32_t samples, uint32_t flags, int sync_after, uint32_t iters = 1,
+                            uint32_t* host_image = nullptr) {
     const int K = pick_k(samples);
     rtk::TraceParams p = params(samples);
     p.iters = iters;
+    p.image_host = host_image;
     p.flags = flags | (nearest_hit ? rtk::TRACE_NEAREST_HIT : 0u);
     p.image = d_image;
     attach_tile_lists(p, (flags & rtk::TRACE_ZERO_ACC) != 0u);
@@ -436,6 +446,19 @@ struct rt_tracer {
     try {
       use_device();
       bool cleared = false;                                              // :242-243, fused into launch 0
+      // Update hand-off, pipelined: the launch that ends at an update point writes the BGRA8 image
+      // into one of two pinned host images itself; its callback runs after the NEXT launch has been
+      // enqueued, i.e. while the GPU is already tracing again (the reference converts, copies and
+      // calls back with the GPU idle, :259-272).  An update whose iteration ran is always delivered,
+      // also when Stop() arrives meanwhile, as in the reference's loop order.
+      struct { bool due = false; uint32_t* image = nullptr; rt_callback_fn cb = nullptr; void* user = nullptr; } pend;
+      auto deliver = [&] {
+        if (!pend.due) return;
+        HIP_CHECK(hipEventSynchronize(handoff_event));                   // :259
+        pend.cb(pend.image, static_cast<size_t>(npix()) * sizeof(uint32_t), pend.user);   // :272
+        pend.due = false;
+      };
+      uint32_t* final_image = h_image;
       uint32_t i = 0;
       while (!stopped && i < iterationCount) {                           // :246
         rt_callback_fn cb; void* user;
@@ -448,30 +471,40 @@ struct rt_tracer {
         uint32_t e = i;                                                  // last iteration of this launch
         while (e < last_allowed && !is_update(e)) ++e;
         const bool update = is_update(e);
-        const uint32_t flags = (cleared ? 0u : rtk::TRACE_ZERO_ACC) |
-                               ((update || e + 1 == iterationCount) ? rtk::TRACE_EMIT_IMAGE : 0u);
+        const bool emit = update || e + 1 == iterationCount;
+        const uint32_t flags = (cleared ? 0u : rtk::TRACE_ZERO_ACC) | (emit ? rtk::TRACE_EMIT_IMAGE : 0u);
+        uint32_t* const target = emit ? (handoff_next ? h_image_alt : h_image) : nullptr;
+        if (emit && pend.due && pend.image == target) deliver();         // never overwrite an image still to be handed out
         // The reference blocks on every launch (:228), which makes a stop take effect after one
-        // kernel.  Here up to `kWindow` launches are in flight: the host never starves the GPU on
-        // short launches, and a stop still takes effect within a few launches.
-        enqueue_trace_launch(samplesPerIteration, flags, update ? 1 : kWindow, e - i + 1u);   // :249
+        // kernel.  Here up to `kWindow` sampled launches are in flight: the host never starves the
+        // GPU on short launches, and a stop still takes effect within a few launches.
+        enqueue_trace_launch(samplesPerIteration, flags, kWindow, e - i + 1u, target);   // :249
         cleared = true;
+        deliver();                                                       // the previous update, while this launch runs
+        if (emit) { final_image = target; handoff_next ^= 1; }
         if (update) {
-          fetch_image();                                                 // :259-270 (conversion fused)
-          cb(h_image, static_cast<size_t>(npix()) * sizeof(uint32_t), user);              // :272
+          HIP_CHECK(hipEventRecord(handoff_event, stream));
+          pend.due = true; pend.image = target; pend.cb = cb; pend.user = user;
         }
         i = e + 1u;
       }
+      deliver();
       drain_events();
       if (!cleared) {                                                    // no launch ran: plain clear (+ convert below)
         clear_accumulators();
         if (!stopped) convert();
       }
       if (stopped) { HIP_CHECK(hipStreamSynchronize(stream)); return; }   // :280-284, no callback
-      fetch_image();                                                     // :287-295
+      if (cleared && i == iterationCount) {
+        HIP_CHECK(hipStreamSynchronize(stream));                         // the last launch wrote final_image itself
+      } else {
+        fetch_image();                                                   // :287-295 (no launch ran)
+        final_image = h_image;
+      }
       completed = true;
       rt_callback_fn cb; void* user;
       { std::lock_guard<std::mutex> lk(state_mu); cb = finished_cb; user = finished_user; }
-      if (cb != nullptr) cb(h_image, static_cast<size_t>(npix()) * sizeof(uint32_t), user);   // :302-305
+      if (cb != nullptr) cb(final_image, static_cast<size_t>(npix()) * sizeof(uint32_t), user);   // :302-305
     } catch (const HipFail& f) {                                         // :307-314 swallowed, but recorded
       set_error(f.what);
     } catch (...) {
@@ -627,6 +660,7 @@ int rt_tracer_create_ex(const uint32_t imageSize[2], const float cameraPosition[
   rc = guarded(t, [&] {
     t->use_device();
     HIP_CHECK(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&t->handoff_event, hipEventDisableTiming));
     t->create_buffers();
   });
   if (rc != RT_OK) {
@@ -634,6 +668,7 @@ int rt_tracer_create_ex(const uint32_t imageSize[2], const float cameraPosition[
     // a C ABI can do better: report, release, hand back nothing.
     std::string why = t->last_error;
     t->release_buffers();
+    if (t->handoff_event) (void)hipEventDestroy(t->handoff_event);
     if (t->stream) (void)hipStreamDestroy(t->stream);
     delete t;
     set_global_error("rt_tracer_create: " + why);
@@ -666,6 +701,7 @@ void rt_tracer_destroy(rt_tracer* t) {                                   // RayT
   if (t->d_tri_color) (void)hipFree(t->d_tri_color);
   if (t->d_spheres) (void)hipFree(t->d_spheres);
   t->release_buffers();
+  if (t->handoff_event) (void)hipEventDestroy(t->handoff_event);
   if (t->stream) (void)hipStreamDestroy(t->stream);
   delete t;
 }
