@@ -151,6 +151,12 @@ int  rt_tracer_launch(rt_tracer* t, uint32_t samples, int clear_first, int emit_
  * are paid once).  iterations <= rt_tracer_fused_iterations(t, samples) (>= 1; 1 when fusing is unavailable). */
 int  rt_tracer_launch_iterations(rt_tracer* t, uint32_t samples, uint32_t iterations, int clear_first, int emit_image);
 int  rt_tracer_fused_iterations(rt_tracer* t, uint32_t samples);
+/* Second BGRA8 target of the emitting launches of rt_tracer_launch* / rt_tracer_trace_enqueue: a
+ * device-visible buffer of at least rt_tracer_buffer_bytes(t, RT_BUF_IMAGE) bytes (device memory such
+ * as a collective's send buffer, or pinned host memory) that the kernel writes alongside RT_BUF_IMAGE --
+ * no copy afterwards.  NULL switches it off.  The caller orders its consumers behind the launch
+ * (rt_tracer_stream) and keeps the buffer alive. */
+int  rt_tracer_set_image_mirror(rt_tracer* t, void* device_visible_image);
 /* Sum of the durations of the SAMPLED trace launches (HIP events on the tracer's stream, around
  * every 4th launch and every launch the caller waits for: an event pair costs ~5 us per launch) and
  * their number since the last reset; total_ms / launches = mean launch duration.  reset_after != 0

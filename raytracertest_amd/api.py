@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "rt_tracer_stop", "rt_tracer_resize", "rt_tracer_set_camera_parameters",
     "rt_tracer_rotate_camera", "rt_tracer_upload_scene", "rt_tracer_set_update_callback",
     "rt_tracer_set_finished_callback", "rt_tracer_wait", "rt_tracer_set_seed",
-    "rt_tracer_upload_spheres", "rt_tracer_trace_enqueue", "rt_tracer_sync", "rt_tracer_trace_stats", "rt_tracer_launch", "rt_tracer_launch_iterations", "rt_tracer_fused_iterations", "rt_tracer_upload_scene_edges", "rt_pack_normal",
+    "rt_tracer_upload_spheres", "rt_tracer_trace_enqueue", "rt_tracer_sync", "rt_tracer_trace_stats", "rt_tracer_launch", "rt_tracer_launch_iterations", "rt_tracer_fused_iterations", "rt_tracer_set_image_mirror", "rt_tracer_upload_scene_edges", "rt_pack_normal",
     "rt_unpack_normal",
     "rt_tracer_kernel_time", "rt_tracer_read_buffer", "rt_tracer_copy_buffer_to_device", "rt_tracer_copy_buffer_to_device_async",
     "rt_tracer_stream",
@@ -132,6 +132,7 @@ def load_library():
         L.rt_tracer_launch.argtypes = [vp, C.c_uint32, C.c_int, C.c_int]
         L.rt_tracer_launch_iterations.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
         L.rt_tracer_fused_iterations.argtypes = [vp, C.c_uint32]
+        L.rt_tracer_set_image_mirror.argtypes = [vp, vp]
         L.rt_tracer_trace_stats.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64)]
         L.rt_tracer_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
         L.rt_tracer_read_buffer.argtypes = [vp, C.c_int, vp, C.c_size_t]
@@ -270,6 +271,11 @@ class RayTracer:
             self._check(self._lib.rt_tracer_launch(self._h, samples, int(clear_first), int(emit_image)))
         else:
             self._check(self._lib.rt_tracer_launch_iterations(self._h, samples, iterations, int(clear_first), int(emit_image)))
+
+    def SetImageMirror(self, device_visible_ptr):
+        """Emitting Launch/TraceEnqueue launches also write the BGRA8 image to this device-visible
+        buffer (e.g. a collective's send tensor); 0/None switches it off."""
+        self._check(self._lib.rt_tracer_set_image_mirror(self._h, C.c_void_p(device_visible_ptr or 0)))
 
     def FusedIterations(self, samples):
         """How many consecutive iterations one launch may run (1 = no fusing)."""

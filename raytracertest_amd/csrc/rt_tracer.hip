@@ -133,6 +133,7 @@ struct rt_tracer {
   uint32_t* d_rng = nullptr;
   uint32_t* h_image = nullptr;      // pinned, handed to callbacks
   uint32_t* h_image_alt = nullptr;  // second pinned image: update i+1 is produced while the callback reads update i
+  uint32_t* image_mirror = nullptr; // rt_tracer_set_image_mirror: second target of emitting rt_tracer_launch* / trace_enqueue launches
   hipEvent_t handoff_event = nullptr;
   int handoff_next = 0;             // which of the two host images the next emitting launch of a Trace writes
   float4* d_tri = nullptr;          // (e2.xyz,e1.x),(e1.yz,v0.xy) records
@@ -878,10 +879,17 @@ int rt_tracer_trace_enqueue(rt_tracer* t, uint32_t iterationCount, uint32_t samp
       t->enqueue_trace_launch(samplesPerIteration,
                               (i == 0 ? rtk::TRACE_ZERO_ACC : 0u) |
                                   (i + n == iterationCount ? rtk::TRACE_EMIT_IMAGE : 0u),
-                              0, n);
+                              0, n, i + n == iterationCount ? t->image_mirror : nullptr);
       i += n;
     }
   });
+}
+
+int rt_tracer_set_image_mirror(rt_tracer* t, void* device_visible_image) {
+  if (!t) return RT_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(t->api_mu);
+  t->image_mirror = static_cast<uint32_t*>(device_visible_image);
+  return RT_OK;
 }
 
 int rt_tracer_fused_iterations(rt_tracer* t, uint32_t samples) {
@@ -899,7 +907,7 @@ int rt_tracer_launch_iterations(rt_tracer* t, uint32_t samples, uint32_t iterati
     t->cancel_and_join();
     t->use_device();
     t->enqueue_trace_launch(samples, (clear_first ? rtk::TRACE_ZERO_ACC : 0u) | (emit_image ? rtk::TRACE_EMIT_IMAGE : 0u),
-                            0, iterations);
+                            0, iterations, emit_image ? t->image_mirror : nullptr);
   });
 }
 
@@ -910,7 +918,7 @@ int rt_tracer_launch(rt_tracer* t, uint32_t samples, int clear_first, int emit_i
     t->cancel_and_join();
     t->use_device();
     t->enqueue_trace_launch(samples, (clear_first ? rtk::TRACE_ZERO_ACC : 0u) | (emit_image ? rtk::TRACE_EMIT_IMAGE : 0u),
-                            0);
+                            0, 1, emit_image ? t->image_mirror : nullptr);
   });
 }
 

@@ -332,6 +332,25 @@ def test_fused_iterations_equal_separate_launches(rt, orc, name, n_it, spp):
     assert len(updates) == (n_it - 1) // 4
 
 
+def test_image_mirror_receives_the_emitted_image(rt):
+    """rt_tracer_set_image_mirror: the emitting launch writes the BGRA8 image into a caller-owned device
+    buffer too (what the multi-GPU step uses as the gather's send buffer)."""
+    import torch
+    import raytracertest_amd as R
+    W, H = 70, 37
+    g = R.RayTracer((W, H), (0, 0, 0), (0.0, 0.0), 70.0, 3.0, 0.05, seed=3)
+    g.UploadScene(scene("cornell"))
+    mirror = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    g.SetImageMirror(mirror.data_ptr())
+    g.TraceEnqueue(3, 2); g.Sync()
+    assert np.array_equal(mirror.cpu().numpy().view(np.uint32), g.Image())
+    g.SetImageMirror(None)
+    before = mirror.clone()
+    g.TraceEnqueue(1, 2); g.Sync()
+    assert torch.equal(before, mirror) and not np.array_equal(before.cpu().numpy().view(np.uint32), g.Image())
+
+
 def test_trace_enqueue_matches_trace(rt, orc):
     g, o = run_pair(rt, orc, 48, 28, scene("rand300"), 2, 4)
     import raytracertest_amd as R
