@@ -575,3 +575,14 @@ def test_two_rank_rehearsal_of_the_multi_gpu_driver(rt):
     import json
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0 and "cpu_baseline" not in line
+
+
+def test_api_soak_against_a_running_render_thread(rt):
+    """Random Trace/Stop/Resize/camera/scene calls while the render thread runs fused launches and
+    pipelined update hand-offs: no hang, no recorded error, and a final Trace still matches the oracle."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_api.py"), "400", "11"],
+                         capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "last error ''" in out.stdout and "final parity True" in out.stdout, out.stdout
