@@ -129,6 +129,13 @@ void orc_rng_init(uint64_t seed, uint64_t subsequence, uint32_t s[6]) {
     if ((subsequence >> k) & 1u) mat_vec(&g_jump[k], s + 1, s + 1);
 }
 
+/* advance a raw state {d, v0..v4} by `n` subsequences of 2^67 outputs (the skip-ahead of curand_init) */
+void orc_rng_skip_subsequences(uint32_t s[6], uint64_t n) {
+  pthread_once(&g_jump_once, jump_build);
+  for (int k = 0; k < 64 && (n >> k); ++k)
+    if ((n >> k) & 1u) mat_vec(&g_jump[k], s + 1, s + 1);
+}
+
 void orc_rng_step_linear_n(uint32_t v[5], uint64_t n) {
   for (uint64_t i = 0; i < n; ++i) step_v(v);
 }

@@ -45,6 +45,7 @@ extern "C" {
 /* state layout used everywhere in this repo: s[0] = d (Weyl), s[1..5] = v[0..4]     */
 void     orc_rng_seed(uint64_t seed, uint32_t s[6]);                 /* curand_init scratch part   */
 void     orc_rng_init(uint64_t seed, uint64_t subsequence, uint32_t s[6]); /* curand_init(seed,sub,0) */
+void     orc_rng_skip_subsequences(uint32_t s[6], uint64_t n);       /* raw state += n * 2^67 outputs */
 uint32_t orc_rng_next(uint32_t s[6]);                                /* curand()                   */
 float    orc_rng_uniform(uint32_t s[6]);                             /* curand_uniform() in (0,1]  */
 void     orc_rng_jump_columns(uint32_t cols[160 * 5]);               /* T^(2^67) as 160 columns    */

@@ -110,6 +110,19 @@ def rng_init(seed, subsequence):
     return s
 
 
+def rng_seed(seed):
+    s = np.zeros(6, np.uint32)
+    lib().orc_rng_seed.argtypes = [C.c_uint64, C.POINTER(C.c_uint32)]
+    lib().orc_rng_seed(seed, _up(s))
+    return s
+
+
+def rng_skip_subsequences(state, n):
+    lib().orc_rng_skip_subsequences.argtypes = [C.POINTER(C.c_uint32), C.c_uint64]
+    lib().orc_rng_skip_subsequences(_up(state), n)
+    return state
+
+
 def rng_next(state):
     return int(lib().orc_rng_next(_up(state)))
 
