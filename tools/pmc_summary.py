@@ -9,15 +9,15 @@ src = os.path.join(root, "gpurun_out", tag)
 dst = os.path.join(root, "profiles")
 for name in ("bench_c3.json", "bench_c4.json", "bench_c3_under_rocprof.json"):
     shutil.copy(os.path.join(src, name), os.path.join(dst, "%s_%s" % (tag, name)))
-stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
+stats = sorted(glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv")), key=os.path.getmtime, reverse=True)
 shutil.copy(stats[0], os.path.join(dst, "%s_c3_kernel_stats.csv" % tag))
-stats4 = glob.glob(os.path.join(src, "stats_c4", "*", "*kernel_stats.csv"))
+stats4 = sorted(glob.glob(os.path.join(src, "stats_c4", "*", "*kernel_stats.csv")), key=os.path.getmtime, reverse=True)
 if stats4:
     shutil.copy(stats4[0], os.path.join(dst, "%s_c4_kernel_stats.csv" % tag))
 rows = []
 means = {}
 for p in ("pmc_fetch", "pmc_write", "pmc_sq"):
-    f = glob.glob(os.path.join(src, p, "*", "*counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(src, p, "*", "*counter_collection.csv")), key=os.path.getmtime)
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
@@ -41,7 +41,7 @@ json.dump({
     open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
 valu = means[(tk, "SQ_INSTS_VALU")]
 c4 = {}
-f4 = glob.glob(os.path.join(src, "pmc_sq_c4", "*", "*counter_collection.csv"))
+f4 = sorted(glob.glob(os.path.join(src, "pmc_sq_c4", "*", "*counter_collection.csv")), key=os.path.getmtime, reverse=True)
 if f4:
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f4[0])):
