@@ -12,14 +12,17 @@ conversion and -- for N > 1 -- the RCCL gather of the finished tiles to rank 0
 configs[2] = C3 (Cornell-box 32 triangles, thin-lens DoF, 1920x1080, 16 spp), the
 configuration the metric is quoted on.  For N > 1 the frame grows to 1920 x (1080*N) and
 every rank owns one 1080-row band: per-GPU work is fixed ("weak"), no data-path collective
-except the tile gather the north star names.
+except the tile gather the north star names.  --config C5 is BASELINE.json configs[4]: the
+10k-triangle scene at 3840x2160x256 spp as ONE frame split into N row bands ("strong").
 
 Prints ONE JSON line on rank 0 with
   roofline      HBM: algorithmic bytes per launch / live HIP-event kernel time vs 8 TB/s
                 (contractual bound; the path is VALU-bound by construction)
   valu          the binding bound: algorithmic fp32 flops (by the reference's exit points,
                 counted by an instrumented launch) vs the 157.3 TFLOP/s spec peak and vs
-                the lane-FMA rate this device sustains (calibrated live)
+                the lane-FMA rate this device sustains (calibrated live); valu.issue = the
+                VALU instructions the kernel really issued (PMC pass, profiles/valu_issue.json)
+                per second vs the calibrated wave64 instruction rate
   cpu_baseline  the oracle (scalar CPU port of the reference kernel) timed on this box's
                 cores on a bounded sample of the same workload
 """
@@ -103,7 +106,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4"])
+    ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4", "C5"],
+                    help="C3 (default, the metric's configuration; weak scaling for --gpus N); C5 = the C4 scene at 256 spp, "
+                         "ONE 3840x2160 frame split into N row bands (strong scaling, BASELINE configs[4])")
     ap.add_argument("--cpu-rows", type=int, default=-1, help="rows of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-valu", action="store_true", help="skip the instrumented launch + VALU calibration")
     ap.add_argument("--samples-in-flight", type=int, default=0)
@@ -127,7 +132,8 @@ def main():
     tris, spheres = scenes.scene_for(args.config)
     n_tris = tris.shape[0] // 3
 
-    job = RowBandJob(cfg, tris, spheres, world=world, rank=rank, local_rank=local_rank, weak=True,
+    weak = args.config != "C5"
+    job = RowBandJob(cfg, tris, spheres, world=world, rank=rank, local_rank=local_rank, weak=weak,
                      samples_in_flight=args.samples_in_flight, lds_chunk=args.lds_chunk)
     for _ in range(args.warmup):
         job.step()
@@ -143,12 +149,13 @@ def main():
     elapsed = job.max_over_ranks(time.perf_counter() - t0)
 
     kernel_ms, launches = job.tracer.KernelTime(reset=True)
-    rays_per_gpu = cfg["width"] * cfg["height"] * cfg["samples"] * cfg["iterations"]
-    value = rays_per_gpu * world * args.steps / elapsed / 1e6
+    rays_per_gpu = cfg["width"] * job.rows * cfg["samples"] * cfg["iterations"]      # this rank's band
+    total_rays = cfg["width"] * cfg["height"] * (world if weak else 1) * cfg["samples"] * cfg["iterations"]
+    value = total_rays * args.steps / elapsed / 1e6
 
     if rank == 0:
         avg_kernel_s = kernel_ms / max(launches, 1) / 1e3
-        b_alg = algorithmic_bytes(cfg["width"], cfg["height"], n_tris, spheres.shape[0])
+        b_alg = algorithmic_bytes(cfg["width"], job.rows, n_tris, spheres.shape[0])        # rank 0's band
         achieved = b_alg / avg_kernel_s / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -158,13 +165,14 @@ def main():
             "metric": "Mray/s at %dx%dx%dspp" % (cfg["width"], cfg["height"], cfg["samples"]),
             "value": round(value, 2), "unit": "Mray/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": {"C2": "C2: 1 sphere, pinhole, 512x512, 1 spp",
                                     "C3": "C3: Cornell-box 32 triangles, thin-lens DoF, 1920x1080, 16 spp",
-                                    "C4": "C4: 10k random triangles, 3840x2160, 64 spp"}[args.config],
+                                    "C4": "C4: 10k random triangles, 3840x2160, 64 spp",
+                                    "C5": "C5: 10k random triangles, 3840x2160, 256 spp, one frame in row bands"}[args.config],
                        "image": "%dx%d per GPU (row band of a %dx%d frame)" % (
-                           cfg["width"], cfg["height"], cfg["width"], cfg["height"] * world),
+                           cfg["width"], job.rows, cfg["width"], cfg["height"] * (world if weak else 1)),
                        "triangles": n_tris, "spheres": int(spheres.shape[0]), "samples_per_launch": cfg["samples"],
                        "launch": job.tracer.Info(), "math_mode": "fma", "rng_seed": cfg["seed"],
                        "sharding": "row bands, RCCL gather of BGRA8 tiles to rank 0" if world > 1 else "single GPU"},
@@ -176,7 +184,7 @@ def main():
                          "note": "contractual bound; the path is fp32-VALU-bound by construction "
                                  "(SURVEY.md 0.5, BASELINE.md 2): see valu"},
         }
-        if not args.no_valu and world == 1:      # (rank 0 must not fall behind its peers before the group is torn down)
+        if not args.no_valu and world == 1 and args.config != "C5":      # (rank 0 must not fall behind its peers before the group is torn down)
             # instrumented launch of the reference's own algorithm (every ray scans the whole list,
             # reference-order tests) on a scratch tracer: exit points per test
             g = R.RayTracer((cfg["width"], cfg["height"]), (0, 0, 0), cfg["angles"], cfg["fov"], cfg["focal"],
@@ -231,7 +239,7 @@ def main():
             out["valu"]["binning"] = {"candidates_per_tile": round(sb["bin_candidates"] / max(sb["bin_rounds"], 1), 2),
                                       "of_triangles": n_tris, "classification_rounds_per_tile": round(sb["bin_rounds"] / waves, 3)}
         if world == 1 and args.cpu_rows != 0:
-            rows = args.cpu_rows if args.cpu_rows > 0 else min(cfg["height"], {"C2": 512, "C3": 1080, "C4": 8}[args.config])
+            rows = args.cpu_rows if args.cpu_rows > 0 else min(cfg["height"], {"C2": 512, "C3": 1080, "C4": 8, "C5": 2}[args.config])
             out["cpu_baseline"] = cpu_baseline(cfg, tris, spheres, rows, host_threads())
         print(json.dumps(out), flush=True)
     job.close()

@@ -575,6 +575,13 @@ def test_two_rank_rehearsal_of_the_multi_gpu_driver(rt):
     import json
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0 and "cpu_baseline" not in line
+    # C5: one 3840x2160 frame, 256 spp, two row bands (strong scaling)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--config", "C5", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and "1080" in line["config"]["image"] and line["value"] > 0
 
 
 def test_api_soak_against_a_running_render_thread(rt):
