@@ -139,6 +139,21 @@ def test_trace_bitexact(rt, orc, mode, name, W, H, it, spp):
     assert_frame_equal(g, o)
 
 
+@pytest.mark.parametrize("W,H", [(1, 1), (1, 70), (70, 1), (7, 3), (33, 9), (257, 5), (5, 129)])
+def test_degenerate_and_ragged_frame_sizes(rt, orc, W, H):
+    """Frames smaller than a tile, one pixel wide/high, and sizes that leave partial tiles on both axes."""
+    g, o = run_pair(rt, orc, W, H, scene("cornell"), 3, 2)
+    assert_frame_equal(g, o)
+    g, o = run_pair(rt, orc, W, H, scene("rand300"), 1, 3, nearest_hit=False)
+    assert_frame_equal(g, o)
+
+
+def test_empty_scene_is_all_background(rt, orc):
+    g, o = run_pair(rt, orc, 45, 31, None, 2, 3)
+    assert_frame_equal(g, o)
+    assert (g.SampleCounts() == 6).all()
+
+
 def test_trace_rotated_camera_and_params(rt, orc):
     import raytracertest_amd as R
     W, H = 64, 40
