@@ -148,6 +148,43 @@ def test_degenerate_and_ragged_frame_sizes(rt, orc, W, H):
     assert_frame_equal(g, o)
 
 
+@pytest.mark.parametrize("cam", [dict(fov=180.0), dict(fov=179.9), dict(fov=0.01), dict(fov=0.0), dict(focal=0.0), dict(focal=1e30),
+                                 dict(aperture=1e6), dict(focal=0.0, aperture=0.0), dict(fov=360.0), dict(fov=-70.0),
+                                 dict(focal=float("inf")), dict(aperture=float("nan"))])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_extreme_camera_parameters_follow_the_oracle_bit_for_bit(rt, orc, cam, mode):
+    """Degenerate cameras (infinite / zero / NaN / negative parameters): whatever the arithmetic yields --
+    inf, NaN, all-miss -- the HIP path and the oracle yield the same values (a NaN matches any NaN: x86 and
+    gfx950 propagate different payloads), with the tile classification switched off by its own non-finite
+    guard where needed."""
+    kw = dict(fov=70.0, focal=3.0, aperture=0.05); kw.update(cam)
+    for name in ("cornell", "rand300"):
+        g, o = run_pair(rt, orc, 40, 24, scene(name), 2, 3, mode=mode, **kw)
+        assert np.array_equal(g.SampleCounts(), o.counts) and np.array_equal(g.RngStates(), o.rng)
+        gr, orr = g.RenderBuffer(), o.render
+        same = (u32(gr) == u32(orr)) | (np.isnan(gr) & np.isnan(orr))
+        assert same.all(), "first differing render values at %s" % np.argwhere(~same)[:4].tolist()
+        assert np.array_equal(g.Image(), o.image)
+
+
+def test_degenerate_spheres_follow_the_oracle(rt, orc):
+    """Radius 0, negative and huge radii, a sphere around the lens, non-finite centres."""
+    sph = np.array([[0.0, 0.0, -5.0, 0.0], [0.5, 0.2, -4.0, -0.7], [0.0, 0.0, 0.0, 2.0], [0.0, 0.0, -50.0, 45.0],
+                    [np.inf, 0.0, -3.0, 1.0], [np.nan, 0.0, -3.0, 1.0], [0.3, -0.4, -2.0, 1e-30]], np.float32)
+    import raytracertest_amd as R
+    for nearest in (False, True):
+        for mode in (0, 1):
+            g = R.RayTracer((48, 30), (0, 0, 0), (0.0, 0.0), 70.0, 3.0, 0.05, seed=1, math_mode=mode, nearest_hit=nearest)
+            o = orc.OracleTracer(48, 30, (0.0, 0.0), 70.0, 3.0, 0.05, seed=1, contract=1 - mode, nthreads=8, hit_mode=int(nearest))
+            g.UploadScene(scene("cornell")); o.upload_scene(scene("cornell"))
+            g.UploadSpheres(sph); o.upload_spheres(sph)
+            g.Trace(2, 2, 0); assert g.Wait(); o.trace(2, 2)
+            gr, orr = g.RenderBuffer(), o.render
+            same = (u32(gr) == u32(orr)) | (np.isnan(gr) & np.isnan(orr))
+            assert same.all(), (nearest, mode, np.argwhere(~same)[:4].tolist())
+            assert np.array_equal(g.Image(), o.image) and np.array_equal(g.RngStates(), o.rng)
+
+
 def test_empty_scene_is_all_background(rt, orc):
     g, o = run_pair(rt, orc, 45, 31, None, 2, 3)
     assert_frame_equal(g, o)
