@@ -185,6 +185,26 @@ def test_degenerate_spheres_follow_the_oracle(rt, orc):
             assert np.array_equal(g.Image(), o.image) and np.array_equal(g.RngStates(), o.rng)
 
 
+def test_several_tracers_render_concurrently(rt, orc):
+    """Four tracers (own streams, own render threads) tracing at the same time on one device."""
+    import raytracertest_amd as R
+    specs = [("cornell", 64, 40, 5, 2, 3), ("rand300", 50, 30, 3, 3, 0), ("demo3", 38, 21, 40, 1, 10), ("cornell", 33, 57, 2, 4, 1)]
+    pairs = []
+    for i, (name, W, H, it, spp, upd) in enumerate(specs):
+        g = R.RayTracer((W, H), (0, 0, 0), (0.0, 0.0), 70.0, 3.0, 0.05, seed=20 + i)
+        o = orc.OracleTracer(W, H, (0.0, 0.0), 70.0, 3.0, 0.05, seed=20 + i, nthreads=4)
+        g.UploadScene(scene(name)); o.upload_scene(scene(name))
+        g.SetUpdateCallback(lambda img, size: None)
+        pairs.append((g, o, it, spp, upd))
+    for rep in range(3):
+        for g, o, it, spp, upd in pairs:
+            g.Trace(it, spp, upd)                       # all four render threads run now
+        for g, o, it, spp, upd in pairs:
+            assert g.Wait()
+            o.trace(it, spp)
+            assert_frame_equal(g, o)
+
+
 def test_empty_scene_is_all_background(rt, orc):
     g, o = run_pair(rt, orc, 45, 31, None, 2, 3)
     assert_frame_equal(g, o)
