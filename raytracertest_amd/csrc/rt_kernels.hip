@@ -211,7 +211,11 @@ hipError_t launch_prep_triangles(bool fma, bool edges, const float4* verts, uint
 }
 
 uint32_t trace_lds_bytes(const TraceParams& p, bool bin) {
-  if (bin) return 4u * p.bin_list * 40u + (p.n_tris > p.bin_list ? p.block_list * 4u + 160u : 0u);
+  if (bin) {
+    const bool large = p.n_tris > p.bin_list;
+    const uint32_t per_candidate = (large && (p.flags & TRACE_PRETEST)) ? 76u : 40u;
+    return 4u * p.bin_list * per_candidate + (large ? p.block_list * 4u + 160u : 0u);
+  }
   const uint32_t staged = p.n_tris < p.chunk ? p.n_tris : p.chunk;
   return staged * 36u;
 }

@@ -34,6 +34,7 @@ struct TraceParams {
   unsigned long long* timeline;   // experiment builds only (tools/timeline.py): 8 u64 per wave
 #endif
   uint32_t* image_host;     // optional second BGRA8 target in pinned host memory (update hand-off), or null
+  uint32_t  pretest_on;     // host decision: launches OR TRACE_PRETEST into flags (large-scene kernels)
   uint32_t  iters;          // fused launches: consecutive iterations of p.samples samples (>= 1)
   // Macro-tile triangle lists (scenes larger than the per-wave list): written by macro_bin_kernel
   // once per launch, read by the trace kernel's block-level pre-cull instead of the whole scene.
@@ -56,6 +57,8 @@ constexpr uint32_t TRACE_NEAREST_HIT = 4u;
 // instead of classifying (valid while camera, scene and frame are unchanged; the host decides).
 constexpr uint32_t TRACE_LISTS_STORE = 8u;
 constexpr uint32_t TRACE_LISTS_LOAD = 16u;
+// large-scene kernels: per-sample conservative forms per candidate (9 more floats per LDS record)
+constexpr uint32_t TRACE_PRETEST = 32u;
 
 hipError_t launch_rng_init(uint32_t* rng, uint32_t npix, uint32_t p0, const uint32_t seeded[6],
                            const uint32_t* jump, hipStream_t st);

@@ -19,6 +19,7 @@
 //     LDS in chunks and every ray scans all of it.
 #pragma once
 #include <float.h>
+#include <type_traits>
 
 #include "rt_device_math.hpp"
 #include "rt_kernels.hpp"
@@ -337,9 +338,23 @@ __device__ __forceinline__ TileFamily make_family(const TraceParams& p, const Fo
   return f;
 }
 
+// Per-sample forms (FORMS = true, large-scene kernels).  For ONE ray the lens origin is known: do =
+// o - oc exactly (up to the rounding already inside a_r below), only the focal point keeps its box.
+// The same expansion then bounds the ray's own det', U', V' by AFFINE functions of (do.x, do.y),
+//     det_hi(do) = detc - do.N + DR      U_hi/lo(do) = Uc + do.(G x e2) +- UR      V_hi/lo(do) = Vc + do.(e1 x G) +- VR
+// with radii that keep every dF term, the bilinear do x dF terms at their family-wide bound and the
+// same rounding allowance c.  The drop rules above, applied to that single ray, become three forms
+//     F1 = U_hi + 1e-6 det_hi        F2 = V_hi + 1e-6 det_hi        F3 = 1.0002 det_hi - U_lo - V_lo
+// (if det_hi <= 0 the ray is culled and any verdict is right): F_i(do) < 0 for some i  =>  the
+// reference's test misses for this ray.  forms[] = {F1.c0, F1.cx, F1.cy, F2.c0, F2.cx, F2.cy, F3.c0,
+// F3.cx, F3.cy}; the trace loop evaluates them per sample (6 fma + min3 + cmp) and only enters the
+// Moeller-Trumbore stages when some ray of the wave survives -- at C4 89 % of the candidate tests
+// of a sample batch are such wave-wide misses (the candidate list covers the whole lens, one
+// batch only 256 points of it).
 // true = every ray of the family certainly misses this triangle (see the block comment)
-__device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0, V3 e1, V3 e2) {
-  const float c = 4e-6f;
+template <bool FORMS = false>
+__device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0, V3 e1, V3 e2, float* forms = nullptr) {
+  const float c = FORMS ? 5e-6f : 4e-6f;                            // + the evaluation of the forms themselves
   const float e1v[3] = {e1.x, e1.y, e1.z}, e2v[3] = {e2.x, e2.y, e2.z}, v0v[3] = {v0.x, v0.y, v0.z};
   float E1[3], E2[3], wc[3], W[3], dw[3], tvc[3], T[3], G[3], a[3], r[3];
 #pragma unroll
@@ -356,6 +371,8 @@ __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0,
     G[i] = f.fc[i] - v0v[i];
   }
   float detc = 0.0f, det_rad = 0.0f, Uc = 0.0f, U_rad = 0.0f, Vc = 0.0f, V_rad = 0.0f;
+  float DR = 0.0f, UR = 0.0f, VR = 0.0f;                            // FORMS: radii for a known origin
+  float Nv[3] = {0.0f, 0.0f, 0.0f}, Gu[3] = {0.0f, 0.0f, 0.0f}, Gv[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int j = (i + 1) % 3, k = (i + 2) % 3;                     // cross(x, y)_i = x_j*y_k - y_j*x_k
@@ -378,6 +395,29 @@ __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0,
     U_rad += a[i] * (__builtin_fabsf(Gxe2) + rxe2) + r[i] * __builtin_fabsf(e2xt) + c * (T[i] * Wxe2 + a[i] * Gabs);
     Vc += wc[i] * txe1;
     V_rad += a[i] * __builtin_fabsf(e1xG) + r[i] * (__builtin_fabsf(txe1) + axe1) + c * (W[i] * Txe1 + a[i] * Gabs);
+    if constexpr (FORMS) {
+      // a_r: what is left of |do_i| once the sample's own origin is used -- the roundings of o = pos + off
+      // and of o - v0 (the aperture part A of orad is the known do itself)
+      const float a_r = 1e-6f * __builtin_fabsf(f.oc[i]) + 2e-7f * (__builtin_fabsf(f.oc[i]) + __builtin_fabsf(v0v[i]));
+      const float dw_r = r[i] + a_r + 2e-7f * (__builtin_fabsf(f.fc[i]) + __builtin_fabsf(f.oc[i]));
+      DR += dw_r * __builtin_fabsf(N_i) + c * (W[i] * Nabs);
+      UR += a_r * __builtin_fabsf(Gxe2) + a[i] * rxe2 + r[i] * __builtin_fabsf(e2xt) + c * (T[i] * Wxe2 + a[i] * Gabs);
+      VR += a_r * __builtin_fabsf(e1xG) + r[i] * (__builtin_fabsf(txe1) + axe1) + c * (W[i] * Txe1 + a[i] * Gabs);
+      Nv[i] = N_i; Gu[i] = Gxe2; Gv[i] = e1xG;
+    }
+  }
+  if constexpr (FORMS) {
+    DR *= 1.00001f; UR *= 1.00001f; VR *= 1.00001f;
+    const float dh = detc + DR;                                     // det_hi at do = 0
+    forms[0] = (Uc + UR) + 1e-6f * dh;                              // F1 = U_hi + 1e-6 det_hi
+    forms[1] = Gu[0] - 1e-6f * Nv[0];
+    forms[2] = Gu[1] - 1e-6f * Nv[1];
+    forms[3] = (Vc + VR) + 1e-6f * dh;                              // F2 = V_hi + 1e-6 det_hi
+    forms[4] = Gv[0] - 1e-6f * Nv[0];
+    forms[5] = Gv[1] - 1e-6f * Nv[1];
+    forms[6] = 1.0002f * dh - (Uc - UR) - (Vc - VR);                // F3 = 1.0002 det_hi - U_lo - V_lo
+    forms[7] = -1.0002f * Nv[0] - Gu[0] - Gv[0];
+    forms[8] = -1.0002f * Nv[1] - Gu[1] - Gv[1];
   }
   det_rad = det_rad * 1.00001f;
   U_rad = U_rad * 1.00001f;
@@ -537,6 +577,7 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2 && !FUSE) ? 5 : RT_TRACE_WA
   unsigned long long st_exit[4] = {0, 0, 0, 0};                    // STATS: lane-tests by exit point
   unsigned long long st_skip[4] = {0, 0, 0, 0};                    // STATS: wave-triangles skipped after A/B/C, reaching D
   unsigned long long st_bin[2] = {0, 0};                           // STATS: candidates kept, classification rounds
+  unsigned long long st_pre = 0;                                   // STATS: candidate tests of a sample batch skipped by the per-sample forms
 
   // ---- full-scan staging (BIN == false) --------------------------------------------------
   const uint32_t cap = n < p.chunk ? n : p.chunk;                  // triangles resident in LDS
@@ -556,6 +597,13 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2 && !FUSE) ? 5 : RT_TRACE_WA
   float4* const cA = s_mem + static_cast<size_t>(wave) * (2u * L);                         // 2 float4 per candidate
   float* const cB = reinterpret_cast<float*>(s_mem + 4u * 2u * L) + wave * L;
   int* const cI = reinterpret_cast<int*>(s_mem + 4u * 2u * L) + 4u * L + wave * L;
+  // PRETEST (large-scene kernels, TRACE_PRETEST): 9 more floats per candidate -- the three per-sample
+  // forms of tile_misses_triangle<true> -- as 2 float4 + 1 float behind the index array
+  constexpr bool PRETEST = BIN && !ONEPASS;
+  const bool pretest = PRETEST && (p.flags & TRACE_PRETEST) != 0u;   // wave-uniform
+  float4* const cF = s_mem + 4u * 2u * L + 2u * L + static_cast<size_t>(wave) * (2u * L);   // after cB, cI (8L floats = 2L float4)
+  float* const cG = reinterpret_cast<float*>(s_mem + 4u * 2u * L + 2u * L + 4u * 2u * L) + wave * L;
+  const uint32_t list_floats4 = pretest ? (4u * 2u * L + 2u * L + 4u * 2u * L + L) : (4u * 2u * L + 2u * L);   // float4 units before the block list
 
   TileFamily fam;
   bool list_complete = false;       // the list in LDS covers the whole scene (classification done once)
@@ -565,7 +613,7 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2 && !FUSE) ? 5 : RT_TRACE_WA
   // indices, in ascending order, in LDS; each wave then only refines that short list against its
   // own tile.  4x fewer classifications and triangle-list reads than every wave scanning the scene.
   const uint32_t Lb = p.block_list;
-  uint32_t* const bI = reinterpret_cast<uint32_t*>(s_mem + 4u * 2u * L) + 8u * L;           // Lb indices
+  uint32_t* const bI = reinterpret_cast<uint32_t*>(s_mem + list_floats4);                    // Lb indices
   uint32_t* const bcnt = bI + Lb;                                                           // 2 x 4 wave counts
   float* const bbox = reinterpret_cast<float*>(bcnt + 8);                                   // 4 waves x (lo[3], hi[3], ok, any)
   uint32_t src_count = n;           // triangles the wave-level classification walks over
@@ -644,7 +692,8 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2 && !FUSE) ? 5 : RT_TRACE_WA
   }
 
   // classify triangles [from, n) until the list is full; returns the first unclassified index
-  auto classify = [&](uint32_t from) -> uint32_t {
+  auto classify = [&](uint32_t from, auto with_forms) -> uint32_t {
+    constexpr bool WF = decltype(with_forms)::value;                // forms only from the call before the sample loop
     uint32_t count = 0, base = from;
     while (base < src_count && count + 64u <= L) {
       const uint32_t e = base + lane;
@@ -657,8 +706,15 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2 && !FUSE) ? 5 : RT_TRACE_WA
       A0 = p.tri_a[2u * ti]; A1 = p.tri_a[2u * ti + 1u];
       bz = p.tri_b[ti];
       bool keep = valid;
-      if (fam.usable)
-        keep = valid && !tile_misses_triangle(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z});
+      float forms[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};   // all-zero forms never reject
+      if (fam.usable) {
+        if constexpr (PRETEST && WF) {
+          if (pretest) keep = valid && !tile_misses_triangle<true>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z}, forms);
+          else keep = valid && !tile_misses_triangle(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z});
+        } else {
+          keep = valid && !tile_misses_triangle(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z});
+        }
+      }
       const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
       const uint32_t pos = count + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
                                                              __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
@@ -667,6 +723,13 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2 && !FUSE) ? 5 : RT_TRACE_WA
         cA[2u * pos + 1u] = A1;
         cB[pos] = bz;
         cI[pos] = static_cast<int>(tri);
+        if constexpr (PRETEST && WF) {
+          if (pretest) {
+            cF[2u * pos] = make_float4(forms[0], forms[1], forms[2], forms[3]);
+            cF[2u * pos + 1u] = make_float4(forms[4], forms[5], forms[6], forms[7]);
+            cG[pos] = forms[8];
+          }
+        }
       }
       count += static_cast<uint32_t>(__builtin_popcountll(m));
       base += 64u;
@@ -704,13 +767,23 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2 && !FUSE) ? 5 : RT_TRACE_WA
       __builtin_amdgcn_wave_barrier();
       list_count = count;
     } else {
-      (void)classify(0u);
+      (void)classify(0u, std::false_type{});
       if (p.flags & TRACE_LISTS_STORE) {
         if (lane == 0u) saved[0] = list_count;
         for (uint32_t e = lane; e < list_count; e += 64u) saved[1u + e] = static_cast<uint32_t>(cI[e]);
       }
     }
     list_complete = true;
+  }
+  // Large scenes: the first classification also runs BEFORE any ray exists (few live registers, and
+  // only here are the per-sample forms computed).  A tile whose candidates fit the list -- nearly
+  // all of them -- never classifies again; one that overflows falls back to rounds inside the
+  // sample loop (lists rebuilt per batch, without forms).
+  bool forms_ready = false;
+  if constexpr (BIN && !ONEPASS) {
+    const uint32_t next0 = classify(0u, std::true_type{});
+    list_complete = next0 >= src_count;
+    forms_ready = pretest && list_complete;
   }
   tl_mark(1);                                                      // family + classification done
   const uint32_t iters = FUSE ? p.iters : 1u;
@@ -732,6 +805,11 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2 && !FUSE) ? 5 : RT_TRACE_WA
       best_i[k] = -1;
     }
 
+    float dox[K], doy[K];                                           // PRETEST: each ray's lens offset do = o - oc
+    if constexpr (PRETEST) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) { dox[k] = o[k].x - p.cam[9]; doy[k] = o[k].y - p.cam[10]; }
+    }
     if constexpr (BIN && ONEPASS) {
       for (uint32_t j = 0; j < list_count; ++j) {                  // ascending triangle order
         const float4 A0 = cA[2u * j], A1 = cA[2u * j + 1u];
@@ -743,10 +821,24 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2 && !FUSE) ? 5 : RT_TRACE_WA
       do {
         uint32_t next = src_count;
         if (!list_complete) {
-          next = classify(base);
-          if (base == 0u && next >= src_count) list_complete = true;
+          next = classify(base, std::false_type{});
         }
         for (uint32_t j = 0; j < list_count; ++j) {                // ascending triangle order
+          if (forms_ready) {
+            // per-sample forms of this candidate at each ray's own lens origin: does ANY ray of the wave survive?
+            const float4 f0 = cF[2u * j], f1 = cF[2u * j + 1u];
+            const float f2 = cG[j];
+            unsigned long long alive = 0ull;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+              const float F1 = __builtin_fmaf(f0.z, doy[k], __builtin_fmaf(f0.y, dox[k], f0.x));
+              const float F2 = __builtin_fmaf(f1.y, doy[k], __builtin_fmaf(f1.x, dox[k], f0.w));
+              const float F3 = __builtin_fmaf(f2, doy[k], __builtin_fmaf(f1.w, dox[k], f1.z));
+              const float worst = __builtin_fminf(__builtin_fminf(F1, F2), F3);
+              alive |= __builtin_amdgcn_ballot_w64(!(worst < 0.0f) && static_cast<uint32_t>(k) < valid_k);
+            }
+            if (alive == 0ull) { if constexpr (STATS) st_pre += 1; continue; }
+          }
           const float4 A0 = cA[2u * j], A1 = cA[2u * j + 1u];
           test_triangle<FMA, K, FILTER, STATS>(A0, A1, [&] { return cB[j]; }, cI[j], o, d, best_t, best_i,
                                                nearest, inside, valid_k, st_exit, st_skip);
@@ -892,6 +984,7 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2 && !FUSE) ? 5 : RT_TRACE_WA
       }
       atomicAdd(p.stats + 8, st_bin[0]);
       atomicAdd(p.stats + 9, st_bin[1]);
+      atomicAdd(p.stats + 10, st_pre);
     }
   }
 }

@@ -247,6 +247,16 @@ struct rt_tracer {
     const char* nb = getenv("RT_MI355X_NO_BLOCK_LIST");
     p.block_list = (n_tris > p.bin_list && !(nb && nb[0] == '1')) ? 1024u : 0u;
     if (p.block_list != 0u && !bin_list_req) p.bin_list = 192u;
+    // Per-sample conservative forms (TRACE_PRETEST) for the large-scene kernels: 76 instead of 40 bytes per
+    // candidate in LDS, so 128 candidates per wave and a 448-entry block list keep the block at 40 KiB
+    // (4 blocks per CU, as before).  Scenes dense enough to overflow 128-entry lists regularly lose more
+    // by the extra classification rounds than the forms save (100 k triangles at 4K: 4.98 -> 5.43 ms),
+    // hence the size limit; C4 (10 k): 5.93 -> 5.66 ms.
+    if (pretest && filter && bin && n_tris > p.bin_list && n_tris <= 50000u) {
+      p.pretest_on = 1u;
+      if (!bin_list_req) p.bin_list = 128u;
+      if (p.block_list != 0u) p.block_list = 448u;
+    }
     return p;
   }
 
@@ -279,7 +289,7 @@ struct rt_tracer {
     rtk::TraceParams p = params(samples);
     p.iters = iters;
     p.image_host = host_image;
-    p.flags = flags | (nearest_hit ? rtk::TRACE_NEAREST_HIT : 0u);
+    p.flags = flags | (nearest_hit ? rtk::TRACE_NEAREST_HIT : 0u) | (p.pretest_on ? rtk::TRACE_PRETEST : 0u);
     p.image = d_image;
     attach_tile_lists(p, (flags & rtk::TRACE_ZERO_ACC) != 0u);
     last_k = K; last_chunk = p.chunk;
@@ -403,6 +413,7 @@ struct rt_tracer {
   uint32_t* d_macro_lists = nullptr;
   size_t macro_lists_words = 0;
   bool macro = true;                  // RT_FLAG_NO_MACRO_BINS / RT_MI355X_NO_MACRO=1 turn it off
+  bool pretest = true;                // RT_MI355X_NO_PRETEST=1 turns the per-sample forms off
   static constexpr uint32_t kMacroW = 128, kMacroH = 64, kMacroCapMax = 65536;
 
   void attach_macro_lists(rtk::TraceParams& p) {
@@ -644,6 +655,7 @@ int rt_tracer_create_ex(const uint32_t imageSize[2], const float cameraPosition[
   t->bin = (opt.flags & RT_FLAG_NO_BINNING) == 0;
   t->nearest_hit = (opt.flags & RT_FLAG_NEAREST_HIT) != 0;
   t->smooth_normals = (opt.flags & RT_FLAG_SMOOTH_NORMALS) != 0;
+  { const char* np = getenv("RT_MI355X_NO_PRETEST"); t->pretest = !(np && np[0] == '1'); }
   if (const char* es = getenv("RT_MI355X_EVENT_STRIDE")) t->event_stride = static_cast<uint32_t>(strtoul(es, nullptr, 10));
   {
     const char* nm = getenv("RT_MI355X_NO_MACRO");
@@ -933,7 +945,7 @@ int rt_tracer_trace_stats(rt_tracer* t, uint32_t samples, uint64_t out[16]) {
     t->clear_accumulators();
     rtk::TraceParams p = t->params(samples);
     p.stats = counters.as<unsigned long long>();
-    p.flags = t->nearest_hit ? rtk::TRACE_NEAREST_HIT : 0u;
+    p.flags = (t->nearest_hit ? rtk::TRACE_NEAREST_HIT : 0u) | (p.pretest_on ? rtk::TRACE_PRETEST : 0u);
     t->attach_macro_lists(p);
     HIP_CHECK(rtk::launch_trace(p, t->fma, t->filter, t->bin, t->pick_k(samples), t->stream));
     HIP_CHECK(hipStreamSynchronize(t->stream));
@@ -1076,7 +1088,7 @@ extern "C" int rt_dbg_trace_timeline(rt_tracer* t, uint32_t samples, unsigned lo
     DevBuf buf(words * sizeof(unsigned long long));
     HIP_CHECK(hipMemsetAsync(buf.p, 0, words * sizeof(unsigned long long), t->stream));
     rtk::TraceParams p = t->params(samples);
-    p.flags = rtk::TRACE_ZERO_ACC | rtk::TRACE_EMIT_IMAGE | (t->nearest_hit ? rtk::TRACE_NEAREST_HIT : 0u);
+    p.flags = rtk::TRACE_ZERO_ACC | rtk::TRACE_EMIT_IMAGE | (t->nearest_hit ? rtk::TRACE_NEAREST_HIT : 0u) | (p.pretest_on ? rtk::TRACE_PRETEST : 0u);
     p.image = t->d_image;
     p.timeline = buf.as<unsigned long long>();
     t->attach_macro_lists(p);
