@@ -16,6 +16,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no built artefacts (they are git-ignored): build the library (hipcc
+    cross-compiles gfx950 without a GPU, ~35 s) and the test oracle once, as __graft_entry__.build() does."""
+    lib = os.environ.get("RT_MI355X_LIB") or os.path.join(ROOT, "raytracertest_amd", "lib", "librt_mi355x.so")
+    orc_lib = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+    if not os.path.exists(lib) or not os.path.exists(orc_lib):
+        import __graft_entry__
+        __graft_entry__.build()
+
+
 def load_kats():
     with open(os.path.join(GOLDEN, "triangle_hit_kats.json")) as f:
         cases = json.load(f)["cases"]
