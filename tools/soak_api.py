@@ -22,7 +22,7 @@ def on_fin(img, size):
 g.SetUpdateCallback(on_up); g.SetFinishedCallback(on_fin)
 t0 = time.time()
 for r in range(rounds):
-    op = rng.integers(0, 8)
+    op = rng.integers(0, 9)
     if op <= 2:
         g.Trace(int(rng.integers(1, 60)), int(rng.integers(1, 4)), int(rng.integers(0, 7)))
     elif op == 3:
@@ -33,9 +33,15 @@ for r in range(rounds):
         d = (float(rng.uniform(-0.2, 0.2)), float(rng.uniform(-0.2, 0.2))); g.RotateCamera(d); angles[0] += d[0]; angles[1] += d[1]
     elif op == 6:
         fov, focal, ap = float(rng.uniform(30, 100)), float(rng.uniform(1, 6)), float(rng.uniform(0, 0.3)); g.SetCameraParameters(fov, focal, ap)
-    else:
+    elif op == 7:
         scn = scenes.random_triangles(int(rng.integers(1, 400)), int(rng.integers(0, 1000))) if rng.integers(0, 2) else scenes.cornell32()
         g.UploadScene(scn)
+    else:                                   # destroy the tracer while its render thread may be running; start over
+        if rng.integers(0, 4) == 0:
+            g.close()
+            angles = [0.0, 0.0]
+            g = R.RayTracer((W, H), (0, 0, 0), tuple(angles), fov, focal, ap, seed=int(rng.integers(0, 100)))
+            g.UploadScene(scn); g.SetUpdateCallback(on_up); g.SetFinishedCallback(on_fin)
     if rng.integers(0, 3) == 0:
         time.sleep(float(rng.uniform(0, 0.003)))
 g.Wait()
