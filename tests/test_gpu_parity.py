@@ -404,6 +404,21 @@ def test_fused_iterations_equal_separate_launches(rt, orc, name, n_it, spp):
     assert len(updates) == (n_it - 1) // 4
 
 
+def test_fused_launch_argument_checks(rt):
+    import raytracertest_amd as R
+    g = R.RayTracer((20, 12), (0, 0, 0), (0.0, 0.0), 70.0, 3.0, 0.05, seed=3)
+    g.UploadScene(scene("cornell"))
+    n = g.FusedIterations(4)
+    assert n == 16 and g.FusedIterations(64) == 1 and g.FusedIterations(100) == 1     # <= 64 samples per pixel per launch
+    g.Launch(4, clear_first=True, emit_image=True, iterations=n); g.Sync()
+    assert (g.SampleCounts() == 4 * n).all()
+    with pytest.raises(R.RtError):
+        g.Launch(4, iterations=n + 1)
+    assert "exceed" in g.LastError()
+    plain = R.RayTracer((20, 12), (0, 0, 0), (0.0, 0.0), 70.0, 3.0, 0.05, seed=3, no_binning=True)
+    assert plain.FusedIterations(1) == 1                      # only the default (classified, filtered) kernels fuse
+
+
 def test_image_mirror_receives_the_emitted_image(rt):
     """rt_tracer_set_image_mirror: the emitting launch writes the BGRA8 image into a caller-owned device
     buffer too (what the multi-GPU step uses as the gather's send buffer)."""
