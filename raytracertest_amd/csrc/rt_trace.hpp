@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256) void macro_bin_kernel(TraceParams p) {
 // additions, so the buffers end bit-identical to p.iters separate launches -- without their
 // state traffic, tile family and classification.  Used between two update points of a Trace.
 template <bool FMA, int K, bool FILTER, bool STATS, bool BIN, bool ONEPASS, bool FUSE = false>
-__global__ __launch_bounds__(256, (ONEPASS && K == 2 && !FUSE) ? 5 : RT_TRACE_WAVES(K)) void trace_kernel(const TraceParams p) {
+__global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) void trace_kernel(const TraceParams p) {
   using M = Math<FMA>;
   extern __shared__ float4 s_mem[];
 
