@@ -213,7 +213,7 @@ hipError_t launch_prep_triangles(bool fma, bool edges, const float4* verts, uint
 uint32_t trace_lds_bytes(const TraceParams& p, bool bin) {
   if (bin) {
     const bool large = p.n_tris > p.bin_list;
-    const uint32_t per_candidate = (large && (p.flags & TRACE_PRETEST)) ? 76u : 40u;
+    const uint32_t per_candidate = (large && (p.flags & TRACE_PRETEST)) ? 104u : 40u;
     return 4u * p.bin_list * per_candidate + (large ? p.block_list * 4u + 160u : 0u);
   }
   const uint32_t staged = p.n_tris < p.chunk ? p.n_tris : p.chunk;
@@ -248,9 +248,18 @@ static void launch_trace_f(const TraceParams& p, bool filter, bool bin, int K, d
   else launch_trace_b<FMA, false, STATS>(p, bin, K, grid, lds, st);
 }
 
+// Large-scene kernels with the per-sample forms (TRACE_PRETEST): filtered + classified only; STATS and FUSE variants
+template <bool FMA, bool STATS, bool FUSE>
+static void launch_trace_pre(const TraceParams& p, int K, dim3 grid, size_t lds, hipStream_t st) {
+#define RT_PRE(KK) hipLaunchKernelGGL((trace_kernel<FMA, KK, true, STATS, true, false, FUSE, true>), grid, dim3(256), lds, st, p)
+  if (K == 1) RT_PRE(1); else if (K == 2) RT_PRE(2); else RT_PRE(4);
+#undef RT_PRE
+}
+
 template <bool FMA>
 static void launch_trace_fused(const TraceParams& p, int K, dim3 grid, size_t lds, hipStream_t st) {
   const bool onepass = p.n_tris <= p.bin_list;
+  if (!onepass && (p.flags & TRACE_PRETEST)) { launch_trace_pre<FMA, false, true>(p, K, grid, lds, st); return; }
 #define RT_FUSED(KK, OP) hipLaunchKernelGGL((trace_kernel<FMA, KK, true, false, true, OP, true>), grid, dim3(256), lds, st, p)
   if (onepass) { if (K == 1) RT_FUSED(1, true); else if (K == 2) RT_FUSED(2, true); else RT_FUSED(4, true); }
   else { if (K == 1) RT_FUSED(1, false); else if (K == 2) RT_FUSED(2, false); else RT_FUSED(4, false); }
@@ -267,6 +276,11 @@ hipError_t launch_trace(const TraceParams& p, bool fma, bool filter, bool bin, i
     if (!trace_can_fuse(filter, bin) || p.stats != nullptr) return hipErrorInvalidValue;
     if (fma) launch_trace_fused<true>(p, K, grid, lds, st);
     else launch_trace_fused<false>(p, K, grid, lds, st);
+    return hipGetLastError();
+  }
+  if ((p.flags & TRACE_PRETEST) && filter && bin && p.n_tris > p.bin_list) {   // large-scene kernels with the per-sample forms
+    if (p.stats != nullptr) { if (fma) launch_trace_pre<true, true, false>(p, K, grid, lds, st); else launch_trace_pre<false, true, false>(p, K, grid, lds, st); }
+    else { if (fma) launch_trace_pre<true, false, false>(p, K, grid, lds, st); else launch_trace_pre<false, false, false>(p, K, grid, lds, st); }
     return hipGetLastError();
   }
   if (p.stats != nullptr) {          // instrumented build of the same kernel (not the timed path)

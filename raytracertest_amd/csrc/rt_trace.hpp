@@ -346,8 +346,13 @@ __device__ __forceinline__ TileFamily make_family(const TraceParams& p, const Fo
 // same rounding allowance c.  The drop rules above, applied to that single ray, become three forms
 //     F1 = U_hi + 1e-6 det_hi        F2 = V_hi + 1e-6 det_hi        F3 = 1.0002 det_hi - U_lo - V_lo
 // (if det_hi <= 0 the ray is culled and any verdict is right): F_i(do) < 0 for some i  =>  the
-// reference's test misses for this ray.  forms[] = {F1.c0, F1.cx, F1.cy, F2.c0, F2.cx, F2.cy, F3.c0,
-// F3.cx, F3.cy}; the trace loop evaluates them per sample (6 fma + min3 + cmp) and only enters the
+// reference's test misses for this ray.  The focal point enters U', V', det' linearly (dF.(e2 x tvc),
+// dF.(tvc x e1), dF.N) apart from the small bilinear do x dF terms, and each lane knows its own
+// dF = F - fc: the linear parts are evaluated per lane from the forms' gradients g_i (kept as bf16,
+// their quantisation and the rounding of dF charged to the constant terms), so that the focal BOX only
+// bounds the bilinear terms -- which is what lifts the rejection from 61 % to ~88 % of C4's tests.
+// forms[] = {F1.c0, F1.cx, F1.cy, F2.c0, F2.cx, F2.cy, F3.c0, F3.cx, F3.cy, g1.xyz, g2.xyz, g3.xyz};
+// the trace loop evaluates F_i = c0 + g.dF (per lane and candidate) + cx do.x + cy do.y (per sample) and only enters the
 // Moeller-Trumbore stages when some ray of the wave survives -- at C4 89 % of the candidate tests
 // of a sample batch are such wave-wide misses (the candidate list covers the whole lens, one
 // batch only 256 points of it).
@@ -373,6 +378,7 @@ __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0,
   float detc = 0.0f, det_rad = 0.0f, Uc = 0.0f, U_rad = 0.0f, Vc = 0.0f, V_rad = 0.0f;
   float DR = 0.0f, UR = 0.0f, VR = 0.0f;                            // FORMS: radii for a known origin
   float Nv[3] = {0.0f, 0.0f, 0.0f}, Gu[3] = {0.0f, 0.0f, 0.0f}, Gv[3] = {0.0f, 0.0f, 0.0f};
+  float Eu[3] = {0.0f, 0.0f, 0.0f}, Ev[3] = {0.0f, 0.0f, 0.0f}, qd[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int j = (i + 1) % 3, k = (i + 2) % 3;                     // cross(x, y)_i = x_j*y_k - y_j*x_k
@@ -399,11 +405,17 @@ __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0,
       // a_r: what is left of |do_i| once the sample's own origin is used -- the roundings of o = pos + off
       // and of o - v0 (the aperture part A of orad is the known do itself)
       const float a_r = 1e-6f * __builtin_fabsf(f.oc[i]) + 2e-7f * (__builtin_fabsf(f.oc[i]) + __builtin_fabsf(v0v[i]));
-      const float dw_r = r[i] + a_r + 2e-7f * (__builtin_fabsf(f.fc[i]) + __builtin_fabsf(f.oc[i]));
+      // The terms LINEAR in dF -- dF.N, dF.(e2 x tvc), dF.(tvc x e1) -- are not bounded over the box but
+      // evaluated per lane from its own dF = F - fc (gradients Eu, Ev, N below); only the bilinear
+      // do x dF terms keep their family-wide bound.
+      const float dw_r = a_r + 2e-7f * (__builtin_fabsf(f.fc[i]) + __builtin_fabsf(f.oc[i]));
       DR += dw_r * __builtin_fabsf(N_i) + c * (W[i] * Nabs);
-      UR += a_r * __builtin_fabsf(Gxe2) + a[i] * rxe2 + r[i] * __builtin_fabsf(e2xt) + c * (T[i] * Wxe2 + a[i] * Gabs);
-      VR += a_r * __builtin_fabsf(e1xG) + r[i] * (__builtin_fabsf(txe1) + axe1) + c * (W[i] * Txe1 + a[i] * Gabs);
-      Nv[i] = N_i; Gu[i] = Gxe2; Gv[i] = e1xG;
+      UR += a_r * __builtin_fabsf(Gxe2) + a[i] * rxe2 + c * (T[i] * Wxe2 + a[i] * Gabs);
+      VR += a_r * __builtin_fabsf(e1xG) + r[i] * axe1 + c * (W[i] * Txe1 + a[i] * Gabs);
+      Nv[i] = N_i; Gu[i] = Gxe2; Gv[i] = e1xG; Eu[i] = e2xt; Ev[i] = txe1;
+      // what a lane's dF can be off by: bf16 storage of the gradients (2^-8 relative, on |dF_i| <= r_i) and
+      // the rounding of F - fc itself
+      qd[i] = 0.00390625f * r[i] + 2e-7f * (__builtin_fabsf(f.fc[i]) + r[i]);
     }
   }
   if constexpr (FORMS) {
@@ -418,6 +430,14 @@ __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0,
     forms[6] = 1.0002f * dh - (Uc - UR) - (Vc - VR);                // F3 = 1.0002 det_hi - U_lo - V_lo
     forms[7] = -1.0002f * Nv[0] - Gu[0] - Gv[0];
     forms[8] = -1.0002f * Nv[1] - Gu[1] - Gv[1];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {                                   // gradients with respect to the lane's dF
+      const float g1 = Eu[i] + 1e-6f * Nv[i], g2 = Ev[i] + 1e-6f * Nv[i], g3 = 1.0002f * Nv[i] - Eu[i] - Ev[i];
+      forms[9 + i] = g1; forms[12 + i] = g2; forms[15 + i] = g3;
+      forms[0] += qd[i] * __builtin_fabsf(g1) * 1.00001f;
+      forms[3] += qd[i] * __builtin_fabsf(g2) * 1.00001f;
+      forms[6] += qd[i] * __builtin_fabsf(g3) * 1.00001f;
+    }
   }
   det_rad = det_rad * 1.00001f;
   U_rad = U_rad * 1.00001f;
@@ -525,7 +545,10 @@ __global__ __launch_bounds__(256) void macro_bin_kernel(TraceParams p) {
 // of p.samples samples each: the per-iteration `render += accu` (:141-143) keeps its order of
 // additions, so the buffers end bit-identical to p.iters separate launches -- without their
 // state traffic, tile family and classification.  Used between two update points of a Trace.
-template <bool FMA, int K, bool FILTER, bool STATS, bool BIN, bool ONEPASS, bool FUSE = false>
+// PRE: large-scene kernels (BIN && !ONEPASS) with the per-sample forms; a separate instantiation because
+// the first classification then moves in front of the sample loop and the forms cost registers and code
+// that sparser scenes do not earn back (300-1000 triangles at 1080p: +6-10 % with them, C4: -13 %).
+template <bool FMA, int K, bool FILTER, bool STATS, bool BIN, bool ONEPASS, bool FUSE = false, bool PRE = false>
 __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) void trace_kernel(const TraceParams p) {
   using M = Math<FMA>;
   extern __shared__ float4 s_mem[];
@@ -597,13 +620,14 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   float4* const cA = s_mem + static_cast<size_t>(wave) * (2u * L);                         // 2 float4 per candidate
   float* const cB = reinterpret_cast<float*>(s_mem + 4u * 2u * L) + wave * L;
   int* const cI = reinterpret_cast<int*>(s_mem + 4u * 2u * L) + 4u * L + wave * L;
-  // PRETEST (large-scene kernels, TRACE_PRETEST): 9 more floats per candidate -- the three per-sample
-  // forms of tile_misses_triangle<true> -- as 2 float4 + 1 float behind the index array
-  constexpr bool PRETEST = BIN && !ONEPASS;
+  // PRETEST (large-scene kernels, TRACE_PRETEST): one 64-byte block more per candidate behind the index
+  // array -- the three per-sample forms of tile_misses_triangle<true> (9 floats) and their focal-point
+  // gradients (9 bf16 in 5 dwords), contiguous so that one address register and four ds_read_b128
+  // with immediate offsets fetch them.  L is a multiple of 2 here.
+  constexpr bool PRETEST = PRE && BIN && !ONEPASS;
   const bool pretest = PRETEST && (p.flags & TRACE_PRETEST) != 0u;   // wave-uniform
-  float4* const cF = s_mem + 4u * 2u * L + 2u * L + static_cast<size_t>(wave) * (2u * L);   // after cB, cI (8L floats = 2L float4)
-  float* const cG = reinterpret_cast<float*>(s_mem + 4u * 2u * L + 2u * L + 4u * 2u * L) + wave * L;
-  const uint32_t list_floats4 = pretest ? (4u * 2u * L + 2u * L + 4u * 2u * L + L) : (4u * 2u * L + 2u * L);   // float4 units before the block list
+  float4* const cP = s_mem + 4u * 2u * L + 2u * L + static_cast<size_t>(wave) * (4u * L);   // after cA (8L float4), cB + cI (2L float4)
+  const uint32_t list_floats4 = pretest ? (4u * 2u * L + 2u * L + 16u * L) : (4u * 2u * L + 2u * L);   // float4 units before the block list
 
   TileFamily fam;
   bool list_complete = false;       // the list in LDS covers the whole scene (classification done once)
@@ -695,7 +719,7 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   auto classify = [&](uint32_t from, auto with_forms) -> uint32_t {
     constexpr bool WF = decltype(with_forms)::value;                // forms only from the call before the sample loop
     uint32_t count = 0, base = from;
-    while (base < src_count && count + 64u <= L) {
+    while (base < src_count && count < L) {
       const uint32_t e = base + lane;
       const bool valid = e < src_count;
       const uint32_t ei = valid ? e : (src_count - 1u);
@@ -706,7 +730,8 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
       A0 = p.tri_a[2u * ti]; A1 = p.tri_a[2u * ti + 1u];
       bz = p.tri_b[ti];
       bool keep = valid;
-      float forms[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};   // all-zero forms never reject
+      float forms[18] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f,
+                         0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};   // all-zero forms never reject
       if (fam.usable) {
         if constexpr (PRETEST && WF) {
           if (pretest) keep = valid && !tile_misses_triangle<true>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z}, forms);
@@ -716,6 +741,7 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
         }
       }
       const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+      if (count + static_cast<uint32_t>(__builtin_popcountll(m)) > L) break;   // does not fit: this step opens the next round
       const uint32_t pos = count + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
                                                              __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
       if (keep) {                                                  // ascending order is preserved
@@ -725,9 +751,14 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
         cI[pos] = static_cast<int>(tri);
         if constexpr (PRETEST && WF) {
           if (pretest) {
-            cF[2u * pos] = make_float4(forms[0], forms[1], forms[2], forms[3]);
-            cF[2u * pos + 1u] = make_float4(forms[4], forms[5], forms[6], forms[7]);
-            cG[pos] = forms[8];
+            auto bf = [](float x) {                                  // fp32 -> bf16, round to nearest (ties up)
+              return (__builtin_bit_cast(uint32_t, x) + 0x8000u) >> 16;
+            };
+            auto pk = [&](float hi, float lo) { return __builtin_bit_cast(float, (bf(hi) << 16) | bf(lo)); };
+            cP[4u * pos] = make_float4(forms[0], forms[1], forms[2], forms[3]);
+            cP[4u * pos + 1u] = make_float4(forms[4], forms[5], forms[6], forms[7]);
+            cP[4u * pos + 2u] = make_float4(forms[8], pk(forms[9], forms[10]), pk(forms[11], forms[12]), pk(forms[13], forms[14]));
+            cP[4u * pos + 3u] = make_float4(pk(forms[15], forms[16]), pk(forms[17], 0.0f), 0.0f, 0.0f);
           }
         }
       }
@@ -780,7 +811,7 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   // all of them -- never classifies again; one that overflows falls back to rounds inside the
   // sample loop (lists rebuilt per batch, without forms).
   bool forms_ready = false;
-  if constexpr (BIN && !ONEPASS) {
+  if constexpr (PRETEST) {
     const uint32_t next0 = classify(0u, std::true_type{});
     list_complete = next0 >= src_count;
     forms_ready = pretest && list_complete;
@@ -806,9 +837,11 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
     }
 
     float dox[K], doy[K];                                           // PRETEST: each ray's lens offset do = o - oc
+    float dFx = 0.0f, dFy = 0.0f, dFz = 0.0f;                       // PRETEST: this lane's focal point minus the tile's box centre
     if constexpr (PRETEST) {
 #pragma unroll
       for (int k = 0; k < K; ++k) { dox[k] = o[k].x - p.cam[9]; doy[k] = o[k].y - p.cam[10]; }
+      dFx = focal.x - fam.fc[0]; dFy = focal.y - fam.fc[1]; dFz = focal.z - fam.fc[2];
     }
     if constexpr (BIN && ONEPASS) {
       for (uint32_t j = 0; j < list_count; ++j) {                  // ascending triangle order
@@ -822,20 +855,32 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
         uint32_t next = src_count;
         if (!list_complete) {
           next = classify(base, std::false_type{});
+          if (base == 0u && next >= src_count) list_complete = true;     // (!PRE: the first classification happens here)
         }
         for (uint32_t j = 0; j < list_count; ++j) {                // ascending triangle order
           if (forms_ready) {
             // per-sample forms of this candidate at each ray's own lens origin: does ANY ray of the wave survive?
-            const float4 f0 = cF[2u * j], f1 = cF[2u * j + 1u];
-            const float f2 = cG[j];
+            const float4 f0 = cP[4u * j], f1 = cP[4u * j + 1u], q2 = cP[4u * j + 2u], q3 = cP[4u * j + 3u];
+            const float f2 = q2.x;
+            // gradients: bf16 pairs, unpacked with one VALU op each (no detour over the scalar unit:
+            // readfirstlane + s_and/s_lshl measured slower, the loop is latency-sensitive)
+            auto hi16 = [](uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); };
+            auto lo16 = [](uint32_t w) { return __builtin_bit_cast(float, w << 16); };
+            const uint32_t w0 = __builtin_bit_cast(uint32_t, q2.y), w1 = __builtin_bit_cast(uint32_t, q2.z),
+                           w2 = __builtin_bit_cast(uint32_t, q2.w), w3 = __builtin_bit_cast(uint32_t, q3.x),
+                           w4 = __builtin_bit_cast(uint32_t, q3.y);
+            // per lane and candidate: constant term + gradient . (this lane's focal point - box centre)
+            const float b1 = __builtin_fmaf(hi16(w1), dFz, __builtin_fmaf(lo16(w0), dFy, __builtin_fmaf(hi16(w0), dFx, f0.x)));
+            const float b2 = __builtin_fmaf(lo16(w2), dFz, __builtin_fmaf(hi16(w2), dFy, __builtin_fmaf(lo16(w1), dFx, f0.w)));
+            const float b3 = __builtin_fmaf(hi16(w4), dFz, __builtin_fmaf(lo16(w3), dFy, __builtin_fmaf(hi16(w3), dFx, f1.z)));
             unsigned long long alive = 0ull;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-              const float F1 = __builtin_fmaf(f0.z, doy[k], __builtin_fmaf(f0.y, dox[k], f0.x));
-              const float F2 = __builtin_fmaf(f1.y, doy[k], __builtin_fmaf(f1.x, dox[k], f0.w));
-              const float F3 = __builtin_fmaf(f2, doy[k], __builtin_fmaf(f1.w, dox[k], f1.z));
+              const float F1 = __builtin_fmaf(f0.z, doy[k], __builtin_fmaf(f0.y, dox[k], b1));
+              const float F2 = __builtin_fmaf(f1.y, doy[k], __builtin_fmaf(f1.x, dox[k], b2));
+              const float F3 = __builtin_fmaf(f2, doy[k], __builtin_fmaf(f1.w, dox[k], b3));
               const float worst = __builtin_fminf(__builtin_fminf(F1, F2), F3);
-              alive |= __builtin_amdgcn_ballot_w64(!(worst < 0.0f) && static_cast<uint32_t>(k) < valid_k);
+              alive |= __builtin_amdgcn_ballot_w64(!(worst < 0.0f) && inside && static_cast<uint32_t>(k) < valid_k);
             }
             if (alive == 0ull) { if constexpr (STATS) st_pre += 1; continue; }
           }

@@ -252,9 +252,10 @@ struct rt_tracer {
     // (4 blocks per CU, as before).  Scenes dense enough to overflow 128-entry lists regularly lose more
     // by the extra classification rounds than the forms save (100 k triangles at 4K: 4.98 -> 5.43 ms),
     // hence the size limit; C4 (10 k): 5.93 -> 5.66 ms.
-    if (pretest && filter && bin && n_tris > p.bin_list && n_tris <= 50000u) {
+    if (pretest && filter && bin && n_tris >= kPretestMinTris && n_tris <= 50000u) {
       p.pretest_on = 1u;
-      if (!bin_list_req) p.bin_list = 128u;
+      if (!bin_list_req) p.bin_list = 92u;
+      else p.bin_list = (p.bin_list + 1u) & ~1u;
       if (p.block_list != 0u) p.block_list = 448u;
     }
     return p;
@@ -414,6 +415,8 @@ struct rt_tracer {
   size_t macro_lists_words = 0;
   bool macro = true;                  // RT_FLAG_NO_MACRO_BINS / RT_MI355X_NO_MACRO=1 turn it off
   bool pretest = true;                // RT_MI355X_NO_PRETEST=1 turns the per-sample forms off
+  // the forms pay for themselves on dense scenes only (break-even ~3000 triangles at 1080p; C4: -13 %)
+  static constexpr uint32_t kPretestMinTris = 4096;
   static constexpr uint32_t kMacroW = 128, kMacroH = 64, kMacroCapMax = 65536;
 
   void attach_macro_lists(rtk::TraceParams& p) {
