@@ -452,10 +452,6 @@ __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0,
 }
 
 // ------------------------------------------------------------------------------------
-// The trace kernel.  grid = (ceil(W/32), ceil(rows/8)), block = 256 threads.
-// Dynamic LDS: BIN ? 4 waves * bin_list * 40 bytes (+ block_list * 4 + 160 bytes for the block-level
-// pre-cull) : min(n_tris, chunk) * 36 bytes.
-// ------------------------------------------------------------------------------------
 // Macro level of the triangle classification (scenes larger than the per-wave list).
 // One block per macro tile of macro_w x macro_h pixels (whole trace blocks): the focal points of
 // ALL its pixels, computed exactly as the trace kernel computes them, give the macro tile's ray
@@ -540,6 +536,11 @@ __global__ __launch_bounds__(256) void macro_bin_kernel(TraceParams p) {
   if (threadIdx.x == 0u) out[0] = overflow ? 0xFFFFFFFFu : total;
 }
 
+// ------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------
+// The trace kernel.  grid = (ceil(W/32), ceil(rows/8)), block = 256 threads.
+// Dynamic LDS: BIN ? 4 waves * bin_list * 40 bytes (104 with the per-sample forms, PRE) + block_list * 4
+// + 160 bytes for the block-level pre-cull : min(n_tris, chunk) * 36 bytes  (trace_lds_bytes()).
 // ------------------------------------------------------------------------------------
 // FUSE: the launch runs p.iters consecutive iterations of the host loop (RayTracerImpl.cu:246-249)
 // of p.samples samples each: the per-iteration `render += accu` (:141-143) keeps its order of
