@@ -13,7 +13,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
 bad = 0
 t0 = time.time()
 for it in range(N):
-    n = int(rng.choice([1, 3, 17, 64, 65, 200, 300, 700, 1500, 4000]))
+    n = int(rng.choice([1, 3, 17, 64, 65, 200, 300, 700, 1500, 4000, 4096, 6000, 12000]))   # >= 4096: the dense-scene kernels with per-sample forms
     scale = float(10.0 ** rng.uniform(-2, 2))
     kind = rng.integers(0, 5)
     c = rng.uniform(-1, 1, (n, 1, 3)) * scale * rng.choice([0.3, 1.0, 4.0])
