@@ -23,6 +23,8 @@ Prints ONE JSON line on rank 0 with
                 the lane-FMA rate this device sustains (calibrated live); valu.issue = the
                 VALU instructions the kernel really issued (PMC pass, profiles/valu_issue.json)
                 per second vs the calibrated wave64 instruction rate
+  warm_lists    NOT the headline: the same steps with the library's default list reuse across Traces
+                (the headline steps rebuild their tile candidate lists every time)
   cpu_baseline  the oracle (scalar CPU port of the reference kernel) timed on this box's
                 cores on a bounded sample of the same workload
 """
@@ -135,6 +137,9 @@ def main():
     weak = args.config != "C5"
     job = RowBandJob(cfg, tris, spheres, world=world, rank=rank, local_rank=local_rank, weak=weak,
                      samples_in_flight=args.samples_in_flight, lds_chunk=args.lds_chunk)
+    # Headline: every step is a from-scratch Trace pass -- the tile candidate lists (a camera-dependent
+    # acceleration structure the library keeps between Traces by default) are NOT carried from step to step.
+    job.tracer.SetListReuse(False)
     for _ in range(args.warmup):
         job.step()
     job.finish()
@@ -149,6 +154,26 @@ def main():
     elapsed = job.max_over_ranks(time.perf_counter() - t0)
 
     kernel_ms, launches = job.tracer.KernelTime(reset=True)
+
+    warm = None
+    if world == 1 and args.config in ("C2", "C3"):
+        # the library's default behaviour for repeated Traces of an unchanged view: lists built once, then reused
+        job.tracer.SetListReuse(True)
+        for _ in range(max(args.warmup, 2)):
+            job.step()
+        job.finish()
+        job.tracer.KernelTime(reset=True)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            job.step()
+        job.finish()
+        dt = time.perf_counter() - t1
+        wk_ms, wk_n = job.tracer.KernelTime(reset=True)
+        warm = {"value": round(cfg["width"] * job.rows * cfg["samples"] * cfg["iterations"] * args.steps / dt / 1e6, 2), "unit": "Mray/s",
+                "ms_per_step": round(dt / args.steps * 1e3, 5), "kernel_us": round(wk_ms / max(wk_n, 1) * 1e3, 2),
+                "note": "NOT the headline: same steps with the tile candidate lists kept between Traces (library default, "
+                        "rt_tracer_set_list_reuse): classification and ray-family work happen once, results identical"}
+        job.tracer.SetListReuse(False)
     rays_per_gpu = cfg["width"] * job.rows * cfg["samples"] * cfg["iterations"]      # this rank's band
     total_rays = cfg["width"] * cfg["height"] * (world if weak else 1) * cfg["samples"] * cfg["iterations"]
     value = total_rays * args.steps / elapsed / 1e6
@@ -184,6 +209,8 @@ def main():
                          "note": "contractual bound; the path is fp32-VALU-bound by construction "
                                  "(SURVEY.md 0.5, BASELINE.md 2): see valu"},
         }
+        if warm is not None:
+            out["warm_lists"] = warm
         if not args.no_valu and world == 1 and args.config != "C5":      # (rank 0 must not fall behind its peers before the group is torn down)
             # instrumented launch of the reference's own algorithm (every ray scans the whole list,
             # reference-order tests) on a scratch tracer: exit points per test

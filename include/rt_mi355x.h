@@ -151,6 +151,12 @@ int  rt_tracer_launch(rt_tracer* t, uint32_t samples, int clear_first, int emit_
  * are paid once).  iterations <= rt_tracer_fused_iterations(t, samples) (>= 1; 1 when fusing is unavailable). */
 int  rt_tracer_launch_iterations(rt_tracer* t, uint32_t samples, uint32_t iterations, int clear_first, int emit_image);
 int  rt_tracer_fused_iterations(rt_tracer* t, uint32_t samples);
+/* Small scenes keep each tile's candidate-triangle list (the result of the conservative classification, a
+ * camera-dependent acceleration structure) in device memory.  across_traces != 0 (default): the lists stay
+ * valid from one Trace to the next until the camera, the lens, the scene, the frame or the arithmetic mode
+ * changes; 0: they are reused by the accumulating launches of one Trace only and every Trace classifies
+ * afresh (what bench.py's headline figure uses).  Results are identical either way. */
+int  rt_tracer_set_list_reuse(rt_tracer* t, int across_traces);
 /* Second BGRA8 target of the emitting launches of rt_tracer_launch* / rt_tracer_trace_enqueue: a
  * device-visible buffer of at least rt_tracer_buffer_bytes(t, RT_BUF_IMAGE) bytes (device memory such
  * as a collective's send buffer, or pinned host memory) that the kernel writes alongside RT_BUF_IMAGE --

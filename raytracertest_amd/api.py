@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "rt_tracer_stop", "rt_tracer_resize", "rt_tracer_set_camera_parameters",
     "rt_tracer_rotate_camera", "rt_tracer_upload_scene", "rt_tracer_set_update_callback",
     "rt_tracer_set_finished_callback", "rt_tracer_wait", "rt_tracer_set_seed",
-    "rt_tracer_upload_spheres", "rt_tracer_trace_enqueue", "rt_tracer_sync", "rt_tracer_trace_stats", "rt_tracer_launch", "rt_tracer_launch_iterations", "rt_tracer_fused_iterations", "rt_tracer_set_image_mirror", "rt_tracer_upload_scene_edges", "rt_pack_normal",
+    "rt_tracer_upload_spheres", "rt_tracer_trace_enqueue", "rt_tracer_sync", "rt_tracer_trace_stats", "rt_tracer_launch", "rt_tracer_launch_iterations", "rt_tracer_fused_iterations", "rt_tracer_set_image_mirror", "rt_tracer_set_list_reuse", "rt_tracer_upload_scene_edges", "rt_pack_normal",
     "rt_unpack_normal",
     "rt_tracer_kernel_time", "rt_tracer_read_buffer", "rt_tracer_copy_buffer_to_device", "rt_tracer_copy_buffer_to_device_async",
     "rt_tracer_stream",
@@ -133,6 +133,7 @@ def load_library():
         L.rt_tracer_launch_iterations.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
         L.rt_tracer_fused_iterations.argtypes = [vp, C.c_uint32]
         L.rt_tracer_set_image_mirror.argtypes = [vp, vp]
+        L.rt_tracer_set_list_reuse.argtypes = [vp, C.c_int]
         L.rt_tracer_trace_stats.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64)]
         L.rt_tracer_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
         L.rt_tracer_read_buffer.argtypes = [vp, C.c_int, vp, C.c_size_t]
@@ -271,6 +272,11 @@ class RayTracer:
             self._check(self._lib.rt_tracer_launch(self._h, samples, int(clear_first), int(emit_image)))
         else:
             self._check(self._lib.rt_tracer_launch_iterations(self._h, samples, iterations, int(clear_first), int(emit_image)))
+
+    def SetListReuse(self, across_traces=True):
+        """Keep the tiles' candidate lists from one Trace to the next while nothing they depend on changes
+        (default) or only within one Trace (False: every Trace classifies afresh)."""
+        self._check(self._lib.rt_tracer_set_list_reuse(self._h, 1 if across_traces else 0))
 
     def SetImageMirror(self, device_visible_ptr):
         """Emitting Launch/TraceEnqueue launches also write the BGRA8 image to this device-visible

@@ -654,11 +654,18 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
     }
   }
   const uint32_t n_src = src_count;  // triangles the block-level pre-cull walks over
+  // a launch that loads its tiles' stored candidate lists needs no ray family at all
+  const bool lists_loaded = ONEPASS && (p.flags & TRACE_LISTS_LOAD) != 0u;   // wave-uniform
   if constexpr (BIN) {
     tl_mark(8);                                                    // loads issued, pinhole + focal point done
-    const FocalBounds wb = focal_bounds(focal, inside);
+    FocalBounds wb;
+    wb.ok = false; wb.any = false;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { wb.lo[i] = 0.0f; wb.hi[i] = 0.0f; }
+    if (!lists_loaded) wb = focal_bounds(focal, inside);
     tl_mark(9);
-    fam = make_family(p, wb);
+    if (!lists_loaded) fam = make_family(p, wb);
+    else fam.usable = false;
     tl_mark(10);
     if constexpr (!ONEPASS) {
       if (Lb != 0u) {

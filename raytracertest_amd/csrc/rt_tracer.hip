@@ -379,7 +379,9 @@ struct rt_tracer {
 
   void attach_tile_lists(rtk::TraceParams& p, bool first_launch_of_trace) {
     p.tile_lists = nullptr;
-    if (first_launch_of_trace) return;    // plain classification, nothing stored: a one-launch Trace pays nothing
+    // reuse_across_traces == false (bench.py's headline): the launch that clears the accumulators always
+    // classifies on its own and stores nothing, so a one-launch Trace neither pays for nor profits from the cache
+    if (first_launch_of_trace && !reuse_across_traces) return;
     if (!bin || p.n_tris == 0u || p.n_tris > p.bin_list || getenv("RT_MI355X_NO_LIST_REUSE")) return;
     const size_t tiles = static_cast<size_t>((W + 31u) / 32u) * ((rows + 7u) / 8u) * 4u;
     const size_t words = tiles * (1u + p.bin_list);
@@ -415,6 +417,10 @@ struct rt_tracer {
   size_t macro_lists_words = 0;
   bool macro = true;                  // RT_FLAG_NO_MACRO_BINS / RT_MI355X_NO_MACRO=1 turn it off
   bool pretest = true;                // RT_MI355X_NO_PRETEST=1 turns the per-sample forms off
+  // Stored tile candidate lists (small scenes) survive from one Trace to the next while camera, lens, scene,
+  // frame and arithmetic mode are unchanged -- like any acceleration structure that is rebuilt only when its
+  // inputs change.  rt_tracer_set_list_reuse(t, 0) restricts the reuse to the launches of one Trace.
+  bool reuse_across_traces = true;
   // the forms pay for themselves on dense scenes only (break-even ~3000 triangles at 1080p; C4: -13 %)
   static constexpr uint32_t kPretestMinTris = 4096;
   static constexpr uint32_t kMacroW = 128, kMacroH = 64, kMacroCapMax = 65536;
@@ -898,6 +904,15 @@ int rt_tracer_trace_enqueue(rt_tracer* t, uint32_t iterationCount, uint32_t samp
       i += n;
     }
   });
+}
+
+int rt_tracer_set_list_reuse(rt_tracer* t, int across_traces) {
+  if (!t) return RT_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(t->api_mu);
+  t->cancel_and_join();
+  t->reuse_across_traces = across_traces != 0;
+  t->list_key_valid = false;
+  return RT_OK;
 }
 
 int rt_tracer_set_image_mirror(rt_tracer* t, void* device_visible_image) {
