@@ -113,6 +113,7 @@ def main():
                          "ONE 3840x2160 frame split into N row bands (strong scaling, BASELINE configs[4])")
     ap.add_argument("--cpu-rows", type=int, default=-1, help="rows of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-valu", action="store_true", help="skip the instrumented launch + VALU calibration")
+    ap.add_argument("--no-warm", action="store_true", help="skip the extra warm_lists measurement (profiling runs: headline launches only)")
     ap.add_argument("--samples-in-flight", type=int, default=0)
     ap.add_argument("--lds-chunk", type=int, default=0)
     args = ap.parse_args()
@@ -156,7 +157,7 @@ def main():
     kernel_ms, launches = job.tracer.KernelTime(reset=True)
 
     warm = None
-    if world == 1 and args.config in ("C2", "C3"):
+    if world == 1 and args.config in ("C2", "C3") and not args.no_warm:
         # the library's default behaviour for repeated Traces of an unchanged view: lists built once, then reused
         job.tracer.SetListReuse(True)
         for _ in range(max(args.warmup, 2)):

@@ -8,7 +8,7 @@ TAG=${1:-r01_x}
 export TMPDIR=/tmp
 O=$PWD/gpurun_out/$TAG
 rm -rf "$O"; mkdir -p "$O"
-B="python3 bench.py --cpu-rows 0 --no-valu"
+B="python3 bench.py --cpu-rows 0 --no-valu --no-warm"   # profiled runs: headline launches only
 python3 bench.py > "$O/bench_c3.json" 2> "$O/bench_c3.err" || exit 1
 python3 bench.py --config C4 --steps 20 --warmup 3 > "$O/bench_c4.json" 2> "$O/bench_c4.err" || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- $B --steps 50 --warmup 5 > "$O/stats.log" 2>&1 || exit 1
