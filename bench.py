@@ -205,10 +205,13 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": "trace_kernel", "kernel_us": round(avg_kernel_s * 1e6, 2),
+                         "kernels_per_launch": 2 if job.rows >= 128 and os.environ.get("RT_MI355X_NO_SPLIT") != "1" else 1,
                          "kernel_Mray_s": round(rays_per_gpu / avg_kernel_s / 1e6, 2),
                          "algorithmic_bytes_per_launch": b_alg,
                          "note": "contractual bound; the path is fp32-VALU-bound by construction "
-                                 "(SURVEY.md 0.5, BASELINE.md 2): see valu"},
+                                 "(SURVEY.md 0.5, BASELINE.md 2): see valu.  A launch runs as two half-frame kernels on two "
+                                 "streams that execute concurrently: kernel_us is the sampled duration of one of them (what "
+                                 "rocprofv3 lists per dispatch), achieved = the launch's algorithmic bytes / kernel_us"},
         }
         if warm is not None:
             out["warm_lists"] = warm

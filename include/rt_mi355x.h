@@ -165,7 +165,8 @@ int  rt_tracer_set_list_reuse(rt_tracer* t, int across_traces);
 int  rt_tracer_set_image_mirror(rt_tracer* t, void* device_visible_image);
 /* Sum of the durations of the SAMPLED trace launches (HIP events on the tracer's stream, around
  * every 4th launch and every launch the caller waits for: an event pair costs ~5 us per launch) and
- * their number since the last reset; total_ms / launches = mean launch duration.  reset_after != 0
+ * their number since the last reset; total_ms / launches = mean launch duration -- of a split launch
+ * (see rt_tracer_stream_b) the upper half-frame kernel's, whose execution overlaps the lower half's.  reset_after != 0
  * clears both and makes the next launch a sampled one. */
 int  rt_tracer_kernel_time(rt_tracer* t, double* total_ms, uint64_t* launches, int reset_after);
 /* One instrumented launch (clear + trace of `samples` spp with counters; not a timed path).
@@ -187,6 +188,12 @@ int  rt_tracer_copy_buffer_to_device(rt_tracer* t, int which, void* dst_device, 
  * with events instead of blocking the host. */
 int  rt_tracer_copy_buffer_to_device_async(rt_tracer* t, int which, void* dst_device, size_t bytes);
 void* rt_tracer_stream(rt_tracer* t);
+/* Trace launches of frames of 128 rows or more run as two half-frame kernels, the upper half on
+ * rt_tracer_stream, the lower half on this second stream (consecutive launches then overlap one half's
+ * drain with the other half's work).  Every other entry point orders itself behind both; a driver that
+ * orders its OWN work behind a launch without blocking either stream records one event on each and
+ * waits for both (raytracertest_amd/dist.py), or calls rt_tracer_sync. */
+void* rt_tracer_stream_b(rt_tracer* t);
 void* rt_tracer_device_pointer(rt_tracer* t, int which);
 size_t rt_tracer_buffer_bytes(rt_tracer* t, int which);
 /* Launch geometry actually used: out[0]=K, out[1]=lds_chunk, out[2]=dynamic LDS bytes,

@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "rt_tracer_stop", "rt_tracer_resize", "rt_tracer_set_camera_parameters",
     "rt_tracer_rotate_camera", "rt_tracer_upload_scene", "rt_tracer_set_update_callback",
     "rt_tracer_set_finished_callback", "rt_tracer_wait", "rt_tracer_set_seed",
-    "rt_tracer_upload_spheres", "rt_tracer_trace_enqueue", "rt_tracer_sync", "rt_tracer_trace_stats", "rt_tracer_launch", "rt_tracer_launch_iterations", "rt_tracer_fused_iterations", "rt_tracer_set_image_mirror", "rt_tracer_set_list_reuse", "rt_tracer_upload_scene_edges", "rt_pack_normal",
+    "rt_tracer_upload_spheres", "rt_tracer_trace_enqueue", "rt_tracer_sync", "rt_tracer_trace_stats", "rt_tracer_launch", "rt_tracer_launch_iterations", "rt_tracer_fused_iterations", "rt_tracer_set_image_mirror", "rt_tracer_set_list_reuse", "rt_tracer_stream_b", "rt_tracer_upload_scene_edges", "rt_pack_normal",
     "rt_unpack_normal",
     "rt_tracer_kernel_time", "rt_tracer_read_buffer", "rt_tracer_copy_buffer_to_device", "rt_tracer_copy_buffer_to_device_async",
     "rt_tracer_stream",
@@ -141,6 +141,8 @@ def load_library():
         L.rt_tracer_copy_buffer_to_device_async.argtypes = [vp, C.c_int, vp, C.c_size_t]
         L.rt_tracer_stream.argtypes = [vp]
         L.rt_tracer_stream.restype = vp
+        L.rt_tracer_stream_b.argtypes = [vp]
+        L.rt_tracer_stream_b.restype = vp
         L.rt_tracer_device_pointer.argtypes = [vp, C.c_int]
         L.rt_tracer_device_pointer.restype = vp
         L.rt_tracer_buffer_bytes.argtypes = [vp, C.c_int]
@@ -336,6 +338,10 @@ class RayTracer:
     def Stream(self):
         """The tracer's hipStream_t as an integer (torch.cuda.ExternalStream(ptr) wraps it)."""
         return int(self._lib.rt_tracer_stream(self._h) or 0)
+
+    def StreamB(self):
+        """The second stream, on which the lower half of split trace launches runs (rt_tracer_stream_b)."""
+        return int(self._lib.rt_tracer_stream_b(self._h) or 0)
 
     def Info(self):
         out = np.zeros(8, np.uint32)

@@ -109,7 +109,7 @@ struct Camera {
   }
 };
 
-struct EventPair { hipEvent_t a, b; uint32_t launches; };
+struct EventPair { hipEvent_t a, b, c; uint32_t launches; bool split; };   // c: end of the lower half on stream_b
 
 }  // namespace
 
@@ -126,7 +126,30 @@ struct rt_tracer {
   uint32_t k_req = 0, chunk_req = 0, bin_list_req = 0;
 
   // device state
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;       // primary stream: everything that is not the lower half of a split launch
+  // Trace launches of tall frames are split into two half-frame kernels on two streams: consecutive
+  // launches then overlap one half's drain (falling occupancy at the end of a kernel) with the other half's
+  // bulk -- 146 -> 131 us per back-to-back C3 step (tools/two_stream.py); a pixel's launches stay ordered
+  // because its half always uses the same stream.  main_stream() is the ordering point for everything else.
+  hipStream_t stream_b = nullptr;
+  hipEvent_t join_event = nullptr, fork_event = nullptr;
+  bool b_dirty = false;               // work on stream_b the primary stream has not waited for yet
+  bool a_dirty = false;               // non-launch work on the primary stream that stream_b has not waited for yet
+  bool split_launches = true;         // RT_MI355X_NO_SPLIT=1 turns it off
+
+  void join_b() {                     // primary stream waits for everything enqueued on stream_b
+    if (!b_dirty) return;
+    HIP_CHECK(hipEventRecord(join_event, stream_b));
+    HIP_CHECK(hipStreamWaitEvent(stream, join_event, 0));
+    b_dirty = false;
+  }
+  hipStream_t main_stream() { join_b(); a_dirty = true; return stream; }
+  void fork_b() {                     // stream_b waits for the non-launch work enqueued on the primary stream
+    if (!a_dirty) return;
+    HIP_CHECK(hipEventRecord(fork_event, stream));
+    HIP_CHECK(hipStreamWaitEvent(stream_b, fork_event, 0));
+    a_dirty = false;
+  }
   float4* d_render = nullptr;
   uint32_t* d_counts = nullptr;
   uint32_t* d_image = nullptr;
@@ -196,7 +219,7 @@ struct rt_tracer {
     uint32_t seeded[6];
     rth::seed_state(seed, seeded);
     const uint32_t p0 = row0 * W;                                        // subsequence of the band's first pixel
-    HIP_CHECK(rtk::launch_rng_init(d_rng, npix(), p0, seeded, jump_device(device), stream));
+    HIP_CHECK(rtk::launch_rng_init(d_rng, npix(), p0, seeded, jump_device(device), main_stream()));
   }
 
   void create_buffers() {                                                // ctor :33-40, Resize :96-102
@@ -212,11 +235,11 @@ struct rt_tracer {
     memset(h_image_alt, 0, n * sizeof(uint32_t));
     // the reference leaves new buffers uninitialised until the first Trace clears them; we
     // zero them so that reading before a Trace is defined
-    HIP_CHECK(hipMemsetAsync(d_render, 0, n * sizeof(float4), stream));
-    HIP_CHECK(hipMemsetAsync(d_counts, 0, n * sizeof(uint32_t), stream));
-    HIP_CHECK(hipMemsetAsync(d_image, 0, n * sizeof(uint32_t), stream));
+    HIP_CHECK(hipMemsetAsync(d_render, 0, n * sizeof(float4), main_stream()));
+    HIP_CHECK(hipMemsetAsync(d_counts, 0, n * sizeof(uint32_t), main_stream()));
+    HIP_CHECK(hipMemsetAsync(d_image, 0, n * sizeof(uint32_t), main_stream()));
     create_states();
-    HIP_CHECK(hipStreamSynchronize(stream));
+    HIP_CHECK(hipStreamSynchronize(main_stream()));
   }
 
   rtk::TraceParams params(uint32_t samples) {
@@ -276,6 +299,7 @@ struct rt_tracer {
     EventPair e{};
     HIP_CHECK(hipEventCreate(&e.a));
     HIP_CHECK(hipEventCreate(&e.b));
+    HIP_CHECK(hipEventCreateWithFlags(&e.c, hipEventDisableTiming));
     return e;
   }
 
@@ -285,14 +309,14 @@ struct rt_tracer {
   // sync_after: 0 = none, 1 = wait for this launch (the reference's behaviour, :228),
   // N > 1 = keep at most N launches in flight (wait for the launch N-1 back).
   void enqueue_trace_launch(uint32_t samples, uint32_t flags, int sync_after, uint32_t iters = 1,
-                            uint32_t* host_image = nullptr) {
+                            uint32_t* host_image = nullptr, bool allow_split = true) {
     const int K = pick_k(samples);
     rtk::TraceParams p = params(samples);
     p.iters = iters;
     p.image_host = host_image;
     p.flags = flags | (nearest_hit ? rtk::TRACE_NEAREST_HIT : 0u) | (p.pretest_on ? rtk::TRACE_PRETEST : 0u);
     p.image = d_image;
-    attach_tile_lists(p, (flags & rtk::TRACE_ZERO_ACC) != 0u);
+    const uint32_t list_flags = decide_tile_lists(p, (flags & rtk::TRACE_ZERO_ACC) != 0u);
     last_k = K; last_chunk = p.chunk;
     last_lds = rtk::trace_lds_bytes(p, bin);
     // Event pairs bracket every `event_stride`-th launch (and every launch the caller waits for):
@@ -301,18 +325,35 @@ struct rt_tracer {
     // per iteration) with both events on every launch.  The mean of the sampled launches is what
     // rt_tracer_kernel_time reports; the first launch after a reset is always sampled.
     const bool timed = sync_after == 1 || event_stride <= 1u || (launch_counter++ % event_stride) == 0u;
-    if (!timed) {
-      attach_macro_lists(p);
+    // Tall frames: upper half on the primary stream, lower half on stream_b (see the fields' comment).
+    // The split row is a multiple of 8, each half is a row band of its own (own tile / macro lists).
+    static const uint32_t split_pct = [] { const char* e = getenv("RT_MI355X_SPLIT_PCT"); const long v = e ? strtol(e, nullptr, 10) : 50; return static_cast<uint32_t>(v >= 10 && v <= 90 ? v : 50); }();
+    const uint32_t r0 = (split_launches && allow_split && p.rows >= 128u) ? ((p.rows * split_pct / 100u + 7u) / 8u) * 8u : 0u;
+    EventPair e{};
+    if (timed) { e = take_events(); e.launches = 1; e.split = r0 != 0u; }
+    if (r0 == 0u) {
+      (void)main_stream();                                               // a launch on one stream orders behind both
+      attach_tile_lists(p, 0, list_flags);
+      if (timed) HIP_CHECK(hipEventRecord(e.a, stream));
+      attach_macro_lists(p, 0, stream);                                  // part of the launch: timed with it
       HIP_CHECK(rtk::launch_trace(p, fma, filter, bin, K, stream));
-      return;
+      if (timed) HIP_CHECK(hipEventRecord(e.b, stream));
+    } else {
+      fork_b();
+      rtk::TraceParams half[2] = {sub_band(p, 0u, r0), sub_band(p, r0, p.rows - r0)};
+      hipStream_t st[2] = {stream, stream_b};
+      if (timed) HIP_CHECK(hipEventRecord(e.a, stream));                 // the sampled duration is the upper half-frame kernel's
+      for (int h = 0; h < 2; ++h) {
+        attach_tile_lists(half[h], h, list_flags);
+        attach_macro_lists(half[h], h, st[h]);
+        HIP_CHECK(rtk::launch_trace(half[h], fma, filter, bin, K, st[h]));
+      }
+      if (timed) { HIP_CHECK(hipEventRecord(e.b, stream)); HIP_CHECK(hipEventRecord(e.c, stream_b)); }
+      b_dirty = true;
     }
-    EventPair e = take_events();
-    e.launches = 1;
-    HIP_CHECK(hipEventRecord(e.a, stream));
-    attach_macro_lists(p);                                               // part of the launch: timed with it
-    HIP_CHECK(rtk::launch_trace(p, fma, filter, bin, K, stream));
-    HIP_CHECK(hipEventRecord(e.b, stream));
-    hipEvent_t wait_for = nullptr;
+    if (!timed) return;
+    const EventPair* wait_for = nullptr;
+    EventPair waited{};
     size_t back = 2;
     {
       std::lock_guard<std::mutex> lk(time_mu);
@@ -322,13 +363,25 @@ struct rt_tracer {
       const size_t stride = event_stride > 1u ? event_stride : 1u;
       back = (static_cast<size_t>(sync_after > 1 ? sync_after : 2) + stride - 1u) / stride;
       if (back < 2u) back = 2u;
-      if (sync_after == 1) wait_for = e.b;
-      else if (sync_after > 1 && pending.size() >= back) wait_for = pending[pending.size() - back].b;
+      if (sync_after == 1) { waited = e; wait_for = &waited; }
+      else if (sync_after > 1 && pending.size() >= back) { waited = pending[pending.size() - back]; wait_for = &waited; }
     }
     if (wait_for) {
-      HIP_CHECK(hipEventSynchronize(wait_for));                           // :228
+      HIP_CHECK(hipEventSynchronize(wait_for->b));                        // :228
+      if (wait_for->split) HIP_CHECK(hipEventSynchronize(wait_for->c));
       if (sync_after > 1) drain_events(back - 1u);                        // everything older has finished: recycle
     }
+  }
+
+  // a row band [off, off + n) of a launch as a launch of its own
+  static rtk::TraceParams sub_band(const rtk::TraceParams& p, uint32_t off, uint32_t n) {
+    rtk::TraceParams q = p;
+    const size_t px = static_cast<size_t>(off) * p.W;
+    q.row0 = p.row0 + off; q.rows = n;
+    q.render = p.render + px; q.counts = p.counts + px; q.rng = p.rng + px;    // npix stays the RNG planes' stride
+    q.image = p.image + px;
+    if (p.image_host != nullptr) q.image_host = p.image_host + px;
+    return q;
   }
 
   // account and recycle the event pairs of finished launches, keeping the newest `keep_last`
@@ -346,18 +399,18 @@ struct rt_tracer {
   }
 
   void clear_accumulators() {                                            // :242-243
-    HIP_CHECK(hipMemsetAsync(d_render, 0, static_cast<size_t>(npix()) * sizeof(float4), stream));
-    HIP_CHECK(hipMemsetAsync(d_counts, 0, static_cast<size_t>(npix()) * sizeof(uint32_t), stream));
+    HIP_CHECK(hipMemsetAsync(d_render, 0, static_cast<size_t>(npix()) * sizeof(float4), main_stream()));
+    HIP_CHECK(hipMemsetAsync(d_counts, 0, static_cast<size_t>(npix()) * sizeof(uint32_t), main_stream()));
   }
 
   void convert() {                                                       // RunConverterKernel :189-202
-    HIP_CHECK(rtk::launch_convert(d_render, d_counts, d_image, npix(), stream));
+    HIP_CHECK(rtk::launch_convert(d_render, d_counts, d_image, npix(), main_stream()));
   }
 
   void fetch_image() {                                                   // device image -> pinned host copy
     HIP_CHECK(hipMemcpyAsync(h_image, d_image, static_cast<size_t>(npix()) * sizeof(uint32_t),
-                             hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));                             // :259,:287
+                             hipMemcpyDeviceToHost, main_stream()));
+    HIP_CHECK(hipStreamSynchronize(main_stream()));                             // :259,:287
   }
 
   // Candidate lists (ONEPASS scenes) are kept across launches: the launch that clears the
@@ -377,13 +430,14 @@ struct rt_tracer {
   bool list_key_valid = false;
   uint32_t scene_generation = 0;
 
-  void attach_tile_lists(rtk::TraceParams& p, bool first_launch_of_trace) {
-    p.tile_lists = nullptr;
+  // Decides once per launch whether its tiles load, store or ignore stored candidate lists (returns the
+  // TRACE_LISTS_* flag or 0) and makes sure the buffer holds the whole band's lists.
+  uint32_t decide_tile_lists(const rtk::TraceParams& p, bool first_launch_of_trace) {
     // reuse_across_traces == false (bench.py's headline): the launch that clears the accumulators always
     // classifies on its own and stores nothing, so a one-launch Trace neither pays for nor profits from the cache
-    if (first_launch_of_trace && !reuse_across_traces) return;
-    if (!bin || p.n_tris == 0u || p.n_tris > p.bin_list || getenv("RT_MI355X_NO_LIST_REUSE")) return;
-    const size_t tiles = static_cast<size_t>((W + 31u) / 32u) * ((rows + 7u) / 8u) * 4u;
+    if (first_launch_of_trace && !reuse_across_traces) return 0u;
+    if (!bin || p.n_tris == 0u || p.n_tris > p.bin_list || getenv("RT_MI355X_NO_LIST_REUSE")) return 0u;
+    const size_t tiles = static_cast<size_t>((W + 31u) / 32u) * ((rows + 7u) / 8u + 1u) * 4u;   // (+1: a split adds a partial block row)
     const size_t words = tiles * (1u + p.bin_list);
     if (words > tile_lists_words) {
       if (d_tile_lists) (void)hipFree(d_tile_lists);
@@ -397,15 +451,21 @@ struct rt_tracer {
     k.half_height = p.half_height; k.aspect = p.aspect; k.focal = p.focal; k.aperture = p.aperture;
     k.W = p.W; k.H = p.H; k.row0 = p.row0; k.rows = p.rows; k.bin_list = p.bin_list; k.n_tris = p.n_tris;
     k.scene_generation = scene_generation; k.fma = fma;
-    p.tile_lists = d_tile_lists;
     const bool same = list_key_valid && memcmp(&k, &list_key, sizeof k) == 0;
-    if (same) {
-      p.flags |= rtk::TRACE_LISTS_LOAD;
-    } else {
-      p.flags |= rtk::TRACE_LISTS_STORE;
-      list_key = k;
-      list_key_valid = true;
-    }
+    if (same) return rtk::TRACE_LISTS_LOAD;
+    list_key = k;
+    list_key_valid = true;
+    return rtk::TRACE_LISTS_STORE;
+  }
+
+  // Points one (half-)launch at its slots of the list buffer: a lower half starts behind the upper half's
+  // block rows (the split row is a multiple of 8).
+  void attach_tile_lists(rtk::TraceParams& p, int /*half*/, uint32_t list_flags) {
+    p.tile_lists = nullptr;
+    if (list_flags == 0u) return;
+    const size_t slot_base = static_cast<size_t>((W + 31u) / 32u) * ((p.row0 - row0) / 8u) * 4u;
+    p.tile_lists = d_tile_lists + slot_base * (1u + p.bin_list);
+    p.flags |= list_flags;
   }
 
   // Macro level of the classification (scenes that do not fit the per-wave list): sizes the
@@ -413,8 +473,8 @@ struct rt_tracer {
   // launch.  Every launch re-bins (the camera may have changed; the pass costs N x macro tiles tests).
   uint32_t event_stride = 4;                      // every 4th launch carries timing events (RT_MI355X_EVENT_STRIDE)
   std::atomic<uint32_t> launch_counter{0};
-  uint32_t* d_macro_lists = nullptr;
-  size_t macro_lists_words = 0;
+  uint32_t* d_macro_lists[2] = {nullptr, nullptr};   // one per half of a split launch
+  size_t macro_lists_words[2] = {0, 0};
   bool macro = true;                  // RT_FLAG_NO_MACRO_BINS / RT_MI355X_NO_MACRO=1 turn it off
   bool pretest = true;                // RT_MI355X_NO_PRETEST=1 turns the per-sample forms off
   // Stored tile candidate lists (small scenes) survive from one Trace to the next while camera, lens, scene,
@@ -425,7 +485,7 @@ struct rt_tracer {
   static constexpr uint32_t kPretestMinTris = 4096;
   static constexpr uint32_t kMacroW = 128, kMacroH = 64, kMacroCapMax = 65536;
 
-  void attach_macro_lists(rtk::TraceParams& p) {
+  void attach_macro_lists(rtk::TraceParams& p, int half, hipStream_t st) {
     p.macro_lists = nullptr;
     if (!bin || !macro || p.n_tris <= p.bin_list) return;
     p.macro_w = kMacroW; p.macro_h = kMacroH;
@@ -441,14 +501,14 @@ struct rt_tracer {
       if (v > 0 && static_cast<uint32_t>(v) < p.macro_cap) p.macro_cap = static_cast<uint32_t>(v);
     }
     const size_t words = static_cast<size_t>(p.macro_nx) * ny * (p.macro_cap + 1u);
-    if (words > macro_lists_words) {
-      if (d_macro_lists) (void)hipFree(d_macro_lists);
-      d_macro_lists = nullptr; macro_lists_words = 0;
-      HIP_CHECK(hipMalloc(&d_macro_lists, words * sizeof(uint32_t)));
-      macro_lists_words = words;
+    if (words > macro_lists_words[half]) {                              // (hipFree waits for the device: safe while the other half runs)
+      if (d_macro_lists[half]) (void)hipFree(d_macro_lists[half]);
+      d_macro_lists[half] = nullptr; macro_lists_words[half] = 0;
+      HIP_CHECK(hipMalloc(&d_macro_lists[half], words * sizeof(uint32_t)));
+      macro_lists_words[half] = words;
     }
-    p.macro_lists = d_macro_lists;
-    HIP_CHECK(rtk::launch_macro_bin(p, fma, stream));
+    p.macro_lists = d_macro_lists[half];
+    HIP_CHECK(rtk::launch_macro_bin(p, fma, st));
   }
 
   static constexpr int kWindow = 4;
@@ -499,12 +559,14 @@ struct rt_tracer {
         // The reference blocks on every launch (:228), which makes a stop take effect after one
         // kernel.  Here up to `kWindow` sampled launches are in flight: the host never starves the
         // GPU on short launches, and a stop still takes effect within a few launches.
-        enqueue_trace_launch(samplesPerIteration, flags, kWindow, e - i + 1u, target);   // :249
+        // (not split over two streams: the update hand-off is an ordering point for both halves anyway,
+        //  and fused launches have no drain between their iterations: measured 18.6 vs 20.3 us per iteration)
+        enqueue_trace_launch(samplesPerIteration, flags, kWindow, e - i + 1u, target, false);   // :249
         cleared = true;
         deliver();                                                       // the previous update, while this launch runs
         if (emit) { final_image = target; handoff_next ^= 1; }
         if (update) {
-          HIP_CHECK(hipEventRecord(handoff_event, stream));
+          HIP_CHECK(hipEventRecord(handoff_event, main_stream()));
           pend.due = true; pend.image = target; pend.cb = cb; pend.user = user;
         }
         i = e + 1u;
@@ -515,9 +577,9 @@ struct rt_tracer {
         clear_accumulators();
         if (!stopped) convert();
       }
-      if (stopped) { HIP_CHECK(hipStreamSynchronize(stream)); return; }   // :280-284, no callback
+      if (stopped) { HIP_CHECK(hipStreamSynchronize(main_stream())); return; }   // :280-284, no callback
       if (cleared && i == iterationCount) {
-        HIP_CHECK(hipStreamSynchronize(stream));                         // the last launch wrote final_image itself
+        HIP_CHECK(hipStreamSynchronize(main_stream()));                         // the last launch wrote final_image itself
       } else {
         fetch_image();                                                   // :287-295 (no launch ran)
         final_image = h_image;
@@ -665,6 +727,7 @@ int rt_tracer_create_ex(const uint32_t imageSize[2], const float cameraPosition[
   t->nearest_hit = (opt.flags & RT_FLAG_NEAREST_HIT) != 0;
   t->smooth_normals = (opt.flags & RT_FLAG_SMOOTH_NORMALS) != 0;
   { const char* np = getenv("RT_MI355X_NO_PRETEST"); t->pretest = !(np && np[0] == '1'); }
+  { const char* ns = getenv("RT_MI355X_NO_SPLIT"); t->split_launches = !(ns && ns[0] == '1'); }
   if (const char* es = getenv("RT_MI355X_EVENT_STRIDE")) t->event_stride = static_cast<uint32_t>(strtoul(es, nullptr, 10));
   {
     const char* nm = getenv("RT_MI355X_NO_MACRO");
@@ -682,7 +745,10 @@ int rt_tracer_create_ex(const uint32_t imageSize[2], const float cameraPosition[
   rc = guarded(t, [&] {
     t->use_device();
     HIP_CHECK(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithFlags(&t->stream_b, hipStreamNonBlocking));
     HIP_CHECK(hipEventCreateWithFlags(&t->handoff_event, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&t->join_event, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&t->fork_event, hipEventDisableTiming));
     t->create_buffers();
   });
   if (rc != RT_OK) {
@@ -691,6 +757,9 @@ int rt_tracer_create_ex(const uint32_t imageSize[2], const float cameraPosition[
     std::string why = t->last_error;
     t->release_buffers();
     if (t->handoff_event) (void)hipEventDestroy(t->handoff_event);
+    if (t->join_event) (void)hipEventDestroy(t->join_event);
+    if (t->fork_event) (void)hipEventDestroy(t->fork_event);
+    if (t->stream_b) (void)hipStreamDestroy(t->stream_b);
     if (t->stream) (void)hipStreamDestroy(t->stream);
     delete t;
     set_global_error("rt_tracer_create: " + why);
@@ -712,11 +781,12 @@ void rt_tracer_destroy(rt_tracer* t) {                                   // RayT
   t->stopped = true;
   if (t->thread.joinable()) t->thread.join();
   (void)hipSetDevice(t->device);
+  if (t->stream_b) (void)hipStreamSynchronize(t->stream_b);
   if (t->stream) (void)hipStreamSynchronize(t->stream);
   t->drain_events();
-  for (EventPair& e : t->free_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  for (EventPair& e : t->free_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); (void)hipEventDestroy(e.c); }
   if (t->d_tile_lists) (void)hipFree(t->d_tile_lists);
-  if (t->d_macro_lists) (void)hipFree(t->d_macro_lists);
+  for (int h = 0; h < 2; ++h) if (t->d_macro_lists[h]) (void)hipFree(t->d_macro_lists[h]);
   if (t->d_tri_n) (void)hipFree(t->d_tri_n);
   if (t->d_tri) (void)hipFree(t->d_tri);
   if (t->d_tri_b) (void)hipFree(t->d_tri_b);
@@ -724,6 +794,9 @@ void rt_tracer_destroy(rt_tracer* t) {                                   // RayT
   if (t->d_spheres) (void)hipFree(t->d_spheres);
   t->release_buffers();
   if (t->handoff_event) (void)hipEventDestroy(t->handoff_event);
+  if (t->join_event) (void)hipEventDestroy(t->join_event);
+  if (t->fork_event) (void)hipEventDestroy(t->fork_event);
+  if (t->stream_b) (void)hipStreamDestroy(t->stream_b);
   if (t->stream) (void)hipStreamDestroy(t->stream);
   delete t;
 }
@@ -758,7 +831,7 @@ int rt_tracer_resize(rt_tracer* t, const uint32_t size[2]) {             // :94-
   return guarded(t, [&] {
     t->cancel_and_join();
     t->use_device();
-    HIP_CHECK(hipStreamSynchronize(t->stream));
+    HIP_CHECK(hipStreamSynchronize(t->main_stream()));
     t->release_buffers();
     t->W = size[0];
     if (t->band_mode) {
@@ -797,7 +870,7 @@ static int upload_scene_impl(rt_tracer* t, const rt_float4* hostData, size_t cou
   return guarded(t, [&] {
     t->cancel_and_join();
     t->use_device();
-    HIP_CHECK(hipStreamSynchronize(t->stream));
+    HIP_CHECK(hipStreamSynchronize(t->main_stream()));
     if (t->d_tri) { (void)hipFree(t->d_tri); t->d_tri = nullptr; }       // :128-137
     if (t->d_tri_b) { (void)hipFree(t->d_tri_b); t->d_tri_b = nullptr; }
     if (t->d_tri_color) { (void)hipFree(t->d_tri_color); t->d_tri_color = nullptr; }
@@ -809,10 +882,10 @@ static int upload_scene_impl(rt_tracer* t, const rt_float4* hostData, size_t cou
     HIP_CHECK(hipMalloc(&t->d_tri_b, static_cast<size_t>(n) * sizeof(float)));
     HIP_CHECK(hipMalloc(&t->d_tri_color, static_cast<size_t>(n) * sizeof(float4)));
     if (edges) HIP_CHECK(hipMalloc(&t->d_tri_n, static_cast<size_t>(n) * 3 * sizeof(float4)));
-    HIP_CHECK(hipMemcpyAsync(verts.p, hostData, count * sizeof(float4), hipMemcpyHostToDevice, t->stream));
+    HIP_CHECK(hipMemcpyAsync(verts.p, hostData, count * sizeof(float4), hipMemcpyHostToDevice, t->main_stream()));
     HIP_CHECK(rtk::launch_prep_triangles(t->fma, edges, verts.as<float4>(), n, t->d_tri, t->d_tri_b,
-                                         t->d_tri_color, t->d_tri_n, t->stream));
-    HIP_CHECK(hipStreamSynchronize(t->stream));
+                                         t->d_tri_color, t->d_tri_n, t->main_stream()));
+    HIP_CHECK(hipStreamSynchronize(t->main_stream()));
     t->n_tris = n;
     t->scene_generation++;
   });
@@ -850,7 +923,7 @@ int rt_tracer_upload_spheres(rt_tracer* t, const rt_float4* spheres, size_t coun
   return guarded(t, [&] {
     t->cancel_and_join();
     t->use_device();
-    HIP_CHECK(hipStreamSynchronize(t->stream));
+    HIP_CHECK(hipStreamSynchronize(t->main_stream()));
     if (t->d_spheres) { (void)hipFree(t->d_spheres); t->d_spheres = nullptr; }
     t->n_spheres = 0;
     if (count == 0) return;
@@ -880,7 +953,7 @@ int rt_tracer_set_seed(rt_tracer* t, uint64_t seed) {
     t->use_device();
     t->seed = seed;
     t->create_states();
-    HIP_CHECK(hipStreamSynchronize(t->stream));
+    HIP_CHECK(hipStreamSynchronize(t->main_stream()));
   });
 }
 
@@ -959,14 +1032,14 @@ int rt_tracer_trace_stats(rt_tracer* t, uint32_t samples, uint64_t out[16]) {
     t->cancel_and_join();
     t->use_device();
     DevBuf counters(16 * sizeof(unsigned long long));
-    HIP_CHECK(hipMemsetAsync(counters.p, 0, 16 * sizeof(unsigned long long), t->stream));
+    HIP_CHECK(hipMemsetAsync(counters.p, 0, 16 * sizeof(unsigned long long), t->main_stream()));
     t->clear_accumulators();
     rtk::TraceParams p = t->params(samples);
     p.stats = counters.as<unsigned long long>();
     p.flags = (t->nearest_hit ? rtk::TRACE_NEAREST_HIT : 0u) | (p.pretest_on ? rtk::TRACE_PRETEST : 0u);
-    t->attach_macro_lists(p);
-    HIP_CHECK(rtk::launch_trace(p, t->fma, t->filter, t->bin, t->pick_k(samples), t->stream));
-    HIP_CHECK(hipStreamSynchronize(t->stream));
+    t->attach_macro_lists(p, 0, t->main_stream());
+    HIP_CHECK(rtk::launch_trace(p, t->fma, t->filter, t->bin, t->pick_k(samples), t->main_stream()));
+    HIP_CHECK(hipStreamSynchronize(t->main_stream()));
     HIP_CHECK(hipMemcpy(out, counters.p, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   });
 }
@@ -975,7 +1048,7 @@ int rt_tracer_sync(rt_tracer* t) {
   if (!t) return RT_ERR_INVALID;
   return guarded(t, [&] {
     t->use_device();
-    HIP_CHECK(hipStreamSynchronize(t->stream));
+    HIP_CHECK(hipStreamSynchronize(t->main_stream()));
     t->drain_events();
   });
 }
@@ -996,7 +1069,7 @@ int rt_tracer_read_buffer(rt_tracer* t, int which, void* dst, size_t bytes) {
   if (!t || !dst || buffer_ptr(t, which) == nullptr || bytes > buffer_bytes(t, which)) return RT_ERR_INVALID;
   return guarded(t, [&] {
     t->use_device();
-    HIP_CHECK(hipStreamSynchronize(t->stream));
+    HIP_CHECK(hipStreamSynchronize(t->main_stream()));
     HIP_CHECK(hipMemcpy(dst, buffer_ptr(t, which), bytes, hipMemcpyDeviceToHost));
   });
 }
@@ -1005,8 +1078,8 @@ int rt_tracer_copy_buffer_to_device(rt_tracer* t, int which, void* dst_device, s
   if (!t || !dst_device || buffer_ptr(t, which) == nullptr || bytes > buffer_bytes(t, which)) return RT_ERR_INVALID;
   return guarded(t, [&] {
     t->use_device();
-    HIP_CHECK(hipMemcpyAsync(dst_device, buffer_ptr(t, which), bytes, hipMemcpyDeviceToDevice, t->stream));
-    HIP_CHECK(hipStreamSynchronize(t->stream));
+    HIP_CHECK(hipMemcpyAsync(dst_device, buffer_ptr(t, which), bytes, hipMemcpyDeviceToDevice, t->main_stream()));
+    HIP_CHECK(hipStreamSynchronize(t->main_stream()));
   });
 }
 
@@ -1014,11 +1087,12 @@ int rt_tracer_copy_buffer_to_device_async(rt_tracer* t, int which, void* dst_dev
   if (!t || !dst_device || buffer_ptr(t, which) == nullptr || bytes > buffer_bytes(t, which)) return RT_ERR_INVALID;
   return guarded(t, [&] {
     t->use_device();
-    HIP_CHECK(hipMemcpyAsync(dst_device, buffer_ptr(t, which), bytes, hipMemcpyDeviceToDevice, t->stream));
+    HIP_CHECK(hipMemcpyAsync(dst_device, buffer_ptr(t, which), bytes, hipMemcpyDeviceToDevice, t->main_stream()));
   });
 }
 
 void* rt_tracer_stream(rt_tracer* t) { return t ? static_cast<void*>(t->stream) : nullptr; }
+void* rt_tracer_stream_b(rt_tracer* t) { return t ? static_cast<void*>(t->stream_b) : nullptr; }
 
 int rt_tracer_info(rt_tracer* t, uint32_t out[8]) {
   if (!t || !out) return RT_ERR_INVALID;
@@ -1104,14 +1178,14 @@ extern "C" int rt_dbg_trace_timeline(rt_tracer* t, uint32_t samples, unsigned lo
     const size_t words = static_cast<size_t>((t->W + 31u) / 32u) * ((t->rows + 7u) / 8u) * 4u * 16u;
     if (words > capacity_words) throw HipFail{fmt("timeline needs %zu words", words)};
     DevBuf buf(words * sizeof(unsigned long long));
-    HIP_CHECK(hipMemsetAsync(buf.p, 0, words * sizeof(unsigned long long), t->stream));
+    HIP_CHECK(hipMemsetAsync(buf.p, 0, words * sizeof(unsigned long long), t->main_stream()));
     rtk::TraceParams p = t->params(samples);
     p.flags = rtk::TRACE_ZERO_ACC | rtk::TRACE_EMIT_IMAGE | (t->nearest_hit ? rtk::TRACE_NEAREST_HIT : 0u) | (p.pretest_on ? rtk::TRACE_PRETEST : 0u);
     p.image = t->d_image;
     p.timeline = buf.as<unsigned long long>();
-    t->attach_macro_lists(p);
-    HIP_CHECK(rtk::launch_trace(p, t->fma, t->filter, t->bin, t->pick_k(samples), t->stream));
-    HIP_CHECK(hipStreamSynchronize(t->stream));
+    t->attach_macro_lists(p, 0, t->main_stream());
+    HIP_CHECK(rtk::launch_trace(p, t->fma, t->filter, t->bin, t->pick_k(samples), t->main_stream()));
+    HIP_CHECK(hipStreamSynchronize(t->main_stream()));
     HIP_CHECK(hipMemcpy(out, buf.p, words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   });
 }
@@ -1160,8 +1234,8 @@ int rt_dbg_get_ray(rt_tracer* t, uint32_t n, const uint32_t* pixels, uint32_t* s
     HIP_CHECK(hipMemcpy(dpix.p, pixels, n * 2 * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(ds.p, states, n * 6 * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_CHECK(rtk::launch_dbg_get_ray(t->fma, p, n, dpix.as<uint32_t>(), ds.as<uint32_t>(), dr.as<float>(),
-                                      t->stream));
-    HIP_CHECK(hipStreamSynchronize(t->stream));
+                                      t->main_stream()));
+    HIP_CHECK(hipStreamSynchronize(t->main_stream()));
     HIP_CHECK(hipMemcpy(states, ds.p, n * 6 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(rays, dr.p, n * 6 * sizeof(float), hipMemcpyDeviceToHost));
   });

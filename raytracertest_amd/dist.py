@@ -175,8 +175,11 @@ class RowBandJob:
             self.tiles = [t.zeros((tallest, W), dtype=t.int32, device="cuda") for _ in range(2)]
             self.recv = [[t.empty((tallest, W), dtype=t.int32, device="cuda") for _ in range(world)] for _ in range(2)] \
                 if rank == 0 else [None, None]
-            self.trace_stream = t.cuda.ExternalStream(self.tracer.Stream(), device=t.device("cuda", local_rank))   # the tracer's own HIP stream
-            self.copied = [t.cuda.Event() for _ in range(2)]      # tile i copied (recorded on the tracer's stream)
+            dev = t.device("cuda", local_rank)
+            # the tracer's own HIP streams: trace launches run as two half-frame kernels on two streams
+            self.trace_streams = [t.cuda.ExternalStream(self.tracer.Stream(), device=dev),
+                                  t.cuda.ExternalStream(self.tracer.StreamB(), device=dev)]
+            self.copied = [[t.cuda.Event() for _ in range(2)] for _ in range(2)]   # tile i written, one event per stream
             self.gathered = [t.cuda.Event() for _ in range(2)]    # tile i consumed by the gather (torch's stream)
 
     # ---- throughput path (bench.py) -------------------------------------------------------
@@ -192,12 +195,14 @@ class RowBandJob:
         from .api import BUF_IMAGE
         b = self.step_index & 1
         self.step_index += 1
-        self.trace_stream.wait_event(self.gathered[b])            # buffer b is free again (no-op the first time)
+        for s in self.trace_streams:
+            s.wait_event(self.gathered[b])                        # buffer b is free again (no-op the first time)
         self.tracer.SetImageMirror(self.tiles[b].data_ptr())      # the kernel writes the send buffer itself: no copy
         self.tracer.TraceEnqueue(cfg["iterations"], cfg["samples"])
-        self.copied[b].record(self.trace_stream)
         cur = self.torch.cuda.current_stream()
-        cur.wait_event(self.copied[b])
+        for ev, s in zip(self.copied[b], self.trace_streams):     # the gather waits for both halves, neither stream waits
+            ev.record(s)
+            cur.wait_event(ev)
         if self.backend == "nccl":
             self.dist.gather(self.tiles[b], self.recv[b] if self.rank == 0 else None, dst=0)
         else:                                                    # rehearsal: collective on host copies

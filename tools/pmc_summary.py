@@ -27,6 +27,10 @@ for p in ("pmc_fetch", "pmc_write", "pmc_sq"):
 with open(os.path.join(dst, "%s_c3_pmc_summary.csv" % tag), "w", newline="") as f:
     w = csv.writer(f); w.writerow(["pass", "kernel", "counter", "dispatches", "mean", "min", "max"]); w.writerows(rows)
 tk = [k for (k, c) in means if "trace_kernel" in k][0]
+# a launch of a tall frame runs as two half-frame kernels (two streams): per-LAUNCH figures = per-dispatch means x kernels per launch
+kpl = max(1, round(((1920 + 7) // 8) * ((1080 + 7) // 8) / means[(tk, "SQ_WAVES")]))
+for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES"):
+    means[(tk, c)] *= kpl
 fetch_kb, write_kb = means[(tk, "FETCH_SIZE")], means[(tk, "WRITE_SIZE")]
 npix = 1920 * 1080
 alg = npix * (2 * 24 + 32) + 48 * 32
@@ -49,14 +53,18 @@ if f4:
     m4 = {k: sum(v) / len(v) for k, v in agg.items()}
     t4 = [k for (k, c) in m4 if "trace_kernel" in k][0]
     b4 = [k for (k, c) in m4 if "macro_bin_kernel" in k]
+    kpl4 = max(1, round(((3840 + 7) // 8) * ((2160 + 7) // 8) / m4[(t4, "SQ_WAVES")]))
+    for key in list(m4):
+        if key[0] == t4 or (b4 and key[0] == b4[0]):
+            m4[key] *= kpl4
     v4 = m4[(t4, "SQ_INSTS_VALU")] + (m4[(b4[0], "SQ_INSTS_VALU")] if b4 else 0.0)
-    c4 = {"C4": {"valu_wave_instructions_per_launch": int(v4), "of_which_macro_bin_kernel": int(m4[(b4[0], "SQ_INSTS_VALU")]) if b4 else 0,
+    c4 = {"C4": {"kernels_per_launch": kpl4, "valu_wave_instructions_per_launch": int(v4), "of_which_macro_bin_kernel": int(m4[(b4[0], "SQ_INSTS_VALU")]) if b4 else 0,
                  "waves": int(m4[(t4, "SQ_WAVES")]), "valu_per_wave": round(m4[(t4, "SQ_INSTS_VALU")] / m4[(t4, "SQ_WAVES")], 1),
                  "lane_instructions_per_ray": round(v4 * 64 / (3840 * 2160 * 64), 1)}}
 json.dump({
     "_method": "rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE "
                "(%s, own pass). Per-launch means for the C3 trace kernel; wave-level instruction counts (one count per wave64 instruction)." % tag,
-    "C3": {"valu_wave_instructions_per_launch": int(valu), "salu": int(means[(tk, "SQ_INSTS_SALU")]), "lds": int(means[(tk, "SQ_INSTS_LDS")]),
+    "C3": {"kernels_per_launch": kpl, "valu_wave_instructions_per_launch": int(valu), "salu": int(means[(tk, "SQ_INSTS_SALU")]), "lds": int(means[(tk, "SQ_INSTS_LDS")]),
            "waves": int(means[(tk, "SQ_WAVES")]), "valu_per_wave": round(valu / means[(tk, "SQ_WAVES")], 1),
            "lane_instructions_per_ray": round(valu * 64 / (npix * 16), 1)}, **c4},
     open(os.path.join(dst, "valu_issue.json"), "w"), indent=1)
