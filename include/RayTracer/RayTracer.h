@@ -6,6 +6,7 @@
 // 307-314); LastError() tells what went wrong.  Methods below the marker are additive.
 #pragma once
 #include <cstdint>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -46,13 +47,17 @@ public:
     static_assert(sizeof(float4) == sizeof(rt_float4), "float4 layout");
     if (mImpl) rt_tracer_upload_scene(mImpl, reinterpret_cast<const rt_float4*>(hostData.data()), hostData.size());
   }
+  // (the render thread may be inside OnUpdate/OnFinished meanwhile: the std::function is swapped under a
+  //  mutex and the trampolines call a copy)
   void SetUpdateCallback(rt::CallBackFunction callback) {
-    mUpdate = std::move(callback);
-    rt_tracer_set_update_callback(mImpl, mUpdate ? &RayTracer::OnUpdate : nullptr, this);
+    const bool on = static_cast<bool>(callback);
+    { std::lock_guard<std::mutex> lk(mCallbackMutex); mUpdate = std::move(callback); }
+    rt_tracer_set_update_callback(mImpl, on ? &RayTracer::OnUpdate : nullptr, this);
   }
   void SetFinishedCallback(rt::CallBackFunction callback) {
-    mFinished = std::move(callback);
-    rt_tracer_set_finished_callback(mImpl, mFinished ? &RayTracer::OnFinished : nullptr, this);
+    const bool on = static_cast<bool>(callback);
+    { std::lock_guard<std::mutex> lk(mCallbackMutex); mFinished = std::move(callback); }
+    rt_tracer_set_finished_callback(mImpl, on ? &RayTracer::OnFinished : nullptr, this);
   }
 
   // ---- additive extensions (not in the reference) ---------------------------------------
@@ -63,6 +68,19 @@ public:
     const float pos[3] = {cameraPosition.x, cameraPosition.y, cameraPosition.z};
     const float ang[2] = {cameraAngles.x, cameraAngles.y};
     rt_tracer_create_ex(size, pos, ang, fov, focalLength, aperture, options, &mImpl);
+  }
+  // The frame sharded in row bands over several GPUs of this process, band k on devices[k] (the reference
+  // pins device 0, OpenGLView/GLCanvas.cpp:259-260); same methods, the callbacks receive the whole frame.
+  RayTracer(const math::uvec2& imageSize, const math::vec3& cameraPosition, const math::vec2& cameraAngles,
+            const float fov, const float focalLength, const float aperture, const std::vector<int>& devices,
+            const rt_options* options = nullptr)
+      : mImpl(nullptr) {
+    const uint32_t size[2] = {imageSize.x, imageSize.y};
+    const float pos[3] = {cameraPosition.x, cameraPosition.y, cameraPosition.z};
+    const float ang[2] = {cameraAngles.x, cameraAngles.y};
+    const std::vector<int32_t> devs(devices.begin(), devices.end());
+    rt_tracer_create_multi(size, pos, ang, fov, focalLength, aperture, options, devs.data(),
+                           static_cast<uint32_t>(devs.size()), &mImpl);
   }
   bool Valid() const { return mImpl != nullptr; }
   bool Wait() { return mImpl && rt_tracer_wait(mImpl) == 1; }
@@ -90,13 +108,20 @@ public:
 
 private:
   static void OnUpdate(uint32_t* image, size_t size, void* self) {
-    static_cast<RayTracer*>(self)->mUpdate(image, size);
+    RayTracer* const me = static_cast<RayTracer*>(self);
+    rt::CallBackFunction f;
+    { std::lock_guard<std::mutex> lk(me->mCallbackMutex); f = me->mUpdate; }
+    if (f) f(image, size);
   }
   static void OnFinished(uint32_t* image, size_t size, void* self) {
-    static_cast<RayTracer*>(self)->mFinished(image, size);
+    RayTracer* const me = static_cast<RayTracer*>(self);
+    rt::CallBackFunction f;
+    { std::lock_guard<std::mutex> lk(me->mCallbackMutex); f = me->mFinished; }
+    if (f) f(image, size);
   }
 
   rt_tracer* mImpl;
+  std::mutex mCallbackMutex;
   rt::CallBackFunction mUpdate, mFinished;
 };
 

@@ -56,6 +56,8 @@ extern "C" {
 #define RT_BUF_COUNTS      1   /* rows*W   uint32 sample counts       (mSampleCountBuffer) */
 #define RT_BUF_IMAGE       2   /* rows*W   uint32 BGRA8               (mImageBuffer)       */
 #define RT_BUF_RNG         3   /* 6 planes of rows*W uint32: d, v0..v4 (mRandomStates)     */
+#define RT_BUF_FRAME       4   /* H*W uint32 BGRA8: the gathered frame of a sharded image, on its root only */
+#define RT_GROUP_ID_BYTES  128 /* rt_group_unique_id (an ncclUniqueId)                      */
 
 typedef struct rt_tracer rt_tracer;                      /* opaque: rt::RayTracer + rt::RayTracerImpl */
 typedef struct rt_float4 { float x, y, z, w; } rt_float4;   /* CUDA's float4, RayTracer.h:34 */
@@ -203,6 +205,42 @@ const char* rt_tracer_last_error(rt_tracer* t);
 const char* rt_last_error(void);          /* for failures before a tracer exists */
 int  rt_device_count(void);
 const char* rt_version(void);
+
+/* ---- one frame sharded over several GPUs --------------------------------------
+ * The reference builds ONE rt::RayTracer pinned to device 0 (OpenGLView/MainFrame.cpp:44-45,
+ * OpenGLView/GLCanvas.cpp:259-260).  Pixels are independent and a pixel's RNG stream is keyed by its
+ * global index (Random.cu:21-27), so the frame splits into contiguous row bands -- band k of n owns the rows
+ * [k*H/n, (k+1)*H/n) -- that are traced with no exchange; the finished BGRA8 tiles are gathered to the
+ * root (the device of band 0) with RCCL over xGMI (grouped ncclSend / ncclRecv; tiles of bands on the root
+ * device are written in place by the trace kernel) and handed to the host from there. */
+
+/* Same constructor, device list added: band k runs on devices[k] (ordinals may repeat: several bands per
+ * device).  The handle is an rt_tracer like any other -- Trace / Stop / Resize / SetCameraParameters /
+ * RotateCamera / UploadScene / callbacks keep their meaning, the callbacks receive the WHOLE frame (pinned
+ * host memory) once per update, from one render thread, as in RayTracerImpl.cu:256-305; every device gets
+ * its own host thread for the launches.  rt_tracer_read_buffer returns whole-frame buffers (RT_BUF_IMAGE =
+ * the gathered frame), rt_tracer_trace_enqueue / rt_tracer_launch* include the gather,
+ * rt_tracer_kernel_time reports the first band.  options->device / full_height / row_begin are not used
+ * (full_height must be 0); results are bit-identical to a single tracer on the whole frame. */
+int  rt_tracer_create_multi(const uint32_t imageSize[2], const float cameraPosition[3],
+                            const float cameraAngles[2], float fov, float focalLength, float aperture,
+                            const rt_options* options, const int32_t* devices, uint32_t n_bands,
+                            rt_tracer** out);
+/* One process per GPU instead (torch.distributed.run, MPI ...): every rank creates the tracer of ITS band
+ * (rt_options.full_height / row_begin, rows of rank r of n = [r*H/n, (r+1)*H/n)) and joins the group with the
+ * id rank 0 made and the launcher's own rendezvous distributed (collective: every rank calls it).  From then
+ * on an emitting rt_tracer_trace_enqueue / rt_tracer_launch* of a member is followed by the gather of its
+ * tile to rank 0, on a stream of its own, ordered by events; rt_tracer_sync waits for it as well, and rank 0
+ * reads the gathered frame as RT_BUF_FRAME.  n_ranks == 1 needs no id. */
+int  rt_group_unique_id(uint8_t id[RT_GROUP_ID_BYTES]);
+int  rt_tracer_join_group(rt_tracer* t, uint32_t n_ranks, uint32_t rank, const uint8_t id[RT_GROUP_ID_BYTES]);
+int  rt_tracer_leave_group(rt_tracer* t);
+/* Device time of the gathers since the last reset (root only; HIP events on the root's gather stream around
+ * the exchange) and their number.  Zero for a frame whose bands all live on the root device. */
+int  rt_tracer_gather_time(rt_tracer* t, double* total_ms, uint64_t* gathers, int reset_after);
+/* Bands of the handle (1 for a plain tracer) and where band k runs: out = {device, first row, rows, rank}. */
+int  rt_tracer_band_count(rt_tracer* t);
+int  rt_tracer_band_info(rt_tracer* t, uint32_t band, uint32_t out[4]);
 
 /* ---- single-function device harnesses (parity tests) ---------------------------------- */
 /* n independent (ray, triangle) pairs through the device HitTriangle: rays n*6 (origin,

@@ -22,7 +22,8 @@ FLAG_NO_BINNING = 2
 FLAG_NEAREST_HIT = 4
 FLAG_SMOOTH_NORMALS = 8
 FLAG_NO_MACRO_BINS = 16
-BUF_RENDER, BUF_COUNTS, BUF_IMAGE, BUF_RNG = 0, 1, 2, 3
+BUF_RENDER, BUF_COUNTS, BUF_IMAGE, BUF_RNG, BUF_FRAME = 0, 1, 2, 3, 4
+GROUP_ID_BYTES = 128
 
 # every symbol include/rt_mi355x.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -38,6 +39,8 @@ ABI_SYMBOLS = [
     "rt_tracer_last_error", "rt_last_error", "rt_device_count", "rt_version",
     "rt_dbg_hit_triangle", "rt_dbg_sincos", "rt_dbg_valu_peak", "rt_dbg_check_midrange", "rt_dbg_trace_occupancy", "rt_dbg_uniform", "rt_dbg_get_ray",
     "rt_dbg_rng_init_host",
+    "rt_tracer_create_multi", "rt_group_unique_id", "rt_tracer_join_group", "rt_tracer_leave_group",
+    "rt_tracer_gather_time", "rt_tracer_band_count", "rt_tracer_band_info",
 ]
 
 
@@ -162,12 +165,29 @@ def load_library():
         L.rt_dbg_get_ray.argtypes = [vp, C.c_uint32, u32p, u32p, f32p]
         L.rt_dbg_rng_init_host.argtypes = [C.c_uint64, C.c_uint64, u32p]
         L.rt_dbg_rng_init_host.restype = None
+        L.rt_tracer_create_multi.argtypes = [u32p, f32p, f32p, C.c_float, C.c_float, C.c_float, C.POINTER(Options),
+                                             C.POINTER(C.c_int32), C.c_uint32, C.POINTER(vp)]
+        L.rt_group_unique_id.argtypes = [C.c_char_p]
+        L.rt_tracer_join_group.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_char_p]
+        L.rt_tracer_leave_group.argtypes = [vp]
+        L.rt_tracer_gather_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
+        L.rt_tracer_band_count.argtypes = [vp]
+        L.rt_tracer_band_info.argtypes = [vp, C.c_uint32, u32p]
         _lib = L
         return _lib
 
 
 def device_count():
     return int(load_library().rt_device_count())
+
+
+def group_unique_id():
+    """The id (bytes) rank 0 creates and the launcher's rendezvous hands to every rank for JoinGroup."""
+    buf = C.create_string_buffer(GROUP_ID_BYTES)
+    rc = load_library().rt_group_unique_id(buf)
+    if rc != 0:
+        raise RtError("rt_group_unique_id failed (%d): %s" % (rc, load_library().rt_last_error().decode()))
+    return buf.raw
 
 
 def _f32p(a):
@@ -187,10 +207,13 @@ class RayTracer:
     def __init__(self, imageSize, cameraPosition=(0.0, 0.0, 0.0), cameraAngles=(0.0, 0.0), fov=70.0,
                  focalLength=10.0, aperture=4.0, *, seed=None, device=0, math_mode=MATH_FMA,
                  full_height=0, row_begin=0, no_filter=False, no_binning=False, nearest_hit=False, smooth_normals=False, no_macro_bins=False, samples_in_flight=0,
-                 lds_chunk=0, bin_list=0):
+                 lds_chunk=0, bin_list=0, devices=None):
+        """devices: a list of HIP device ordinals, one per row band -> the frame is sharded over them inside
+        this process (rt_tracer_create_multi; ordinals may repeat); None -> one tracer on `device`."""
         self._lib = load_library()
         self._h = C.c_void_p()
         self._cbs = {}
+        self._retired = []
         size = np.array(imageSize, np.uint32)
         opt = Options()
         opt.struct_size = C.sizeof(Options)
@@ -202,11 +225,19 @@ class RayTracer:
         opt.flags = ((FLAG_NO_FILTER if no_filter else 0) | (FLAG_NO_BINNING if no_binning else 0) |
                      (FLAG_NEAREST_HIT if nearest_hit else 0) | (FLAG_SMOOTH_NORMALS if smooth_normals else 0) | (FLAG_NO_MACRO_BINS if no_macro_bins else 0))
         opt.samples_in_flight, opt.lds_chunk, opt.bin_list = samples_in_flight, lds_chunk, bin_list
-        rc = self._lib.rt_tracer_create_ex(_u32p(size), _f32p(np.array(cameraPosition, np.float32)),
-                                           _f32p(np.array(cameraAngles, np.float32)), fov, focalLength,
-                                           aperture, C.byref(opt), C.byref(self._h))
+        if devices is not None:
+            devs = np.ascontiguousarray(devices, np.int32)
+            rc = self._lib.rt_tracer_create_multi(_u32p(size), _f32p(np.array(cameraPosition, np.float32)),
+                                                  _f32p(np.array(cameraAngles, np.float32)), fov, focalLength, aperture,
+                                                  C.byref(opt), devs.ctypes.data_as(C.POINTER(C.c_int32)), devs.size,
+                                                  C.byref(self._h))
+        else:
+            rc = self._lib.rt_tracer_create_ex(_u32p(size), _f32p(np.array(cameraPosition, np.float32)),
+                                               _f32p(np.array(cameraAngles, np.float32)), fov, focalLength,
+                                               aperture, C.byref(opt), C.byref(self._h))
         if rc != 0 or not self._h:
             raise RtError("rt_tracer_create failed (%d): %s" % (rc, self._lib.rt_last_error().decode()))
+        self.full_height = int(full_height) if full_height else int(size[1])
         self.width = int(size[0])
         self.rows = int(size[1])
 
@@ -255,7 +286,9 @@ class RayTracer:
 
     # ---- extensions ------------------------------------------------------------------
     def Wait(self):
-        return bool(self._lib.rt_tracer_wait(self._h))
+        ok = bool(self._lib.rt_tracer_wait(self._h))
+        self._retired.clear()                  # the render thread has ended: nobody holds a replaced thunk
+        return ok
 
     def SetSeed(self, seed):
         self._check(self._lib.rt_tracer_set_seed(self._h, int(seed)))
@@ -325,6 +358,32 @@ class RayTracer:
         planes = self._read(BUF_RNG, np.uint32, (6, self.rows, self.width))
         return np.ascontiguousarray(np.moveaxis(planes, 0, -1))
 
+    # ---- a frame sharded over several GPUs ------------------------------------------------------
+    def JoinGroup(self, n_ranks, rank, unique_id=None):
+        """This band tracer becomes rank `rank` of `n_ranks` processes that share one frame (collective call)."""
+        self._check(self._lib.rt_tracer_join_group(self._h, n_ranks, rank, unique_id))
+
+    def LeaveGroup(self):
+        self._check(self._lib.rt_tracer_leave_group(self._h))
+
+    def Frame(self):
+        """The gathered (H, W) BGRA8 frame: rank 0 of a group / a multi-device tracer."""
+        return self._read(BUF_FRAME, np.uint32, (self.full_height, self.width))
+
+    def GatherTime(self, reset=True):
+        ms, n = C.c_double(), C.c_uint64()
+        self._lib.rt_tracer_gather_time(self._h, C.byref(ms), C.byref(n), 1 if reset else 0)
+        return ms.value, n.value
+
+    def Bands(self):
+        """[{device, row0, rows, rank}] of the handle's bands (one entry for a plain tracer)."""
+        out = []
+        for k in range(int(self._lib.rt_tracer_band_count(self._h))):
+            v = np.zeros(4, np.uint32)
+            self._check(self._lib.rt_tracer_band_info(self._h, k, _u32p(v)))
+            out.append({"device": int(v[0]), "row0": int(v[1]), "rows": int(v[2]), "rank": int(v[3])})
+        return out
+
     def DevicePointer(self, which):
         return self._lib.rt_tracer_device_pointer(self._h, which)
 
@@ -363,6 +422,7 @@ class RayTracer:
         if self._h:
             self._lib.rt_tracer_destroy(self._h)
             self._h = C.c_void_p()
+            self._retired.clear()
 
     def __del__(self):
         try:
@@ -382,15 +442,21 @@ class RayTracer:
             raise RtError("librt_mi355x error %d: %s" % (rc, self.LastError()))
 
     def _set_cb(self, key, callback, setter):
+        # The render thread snapshots the callback per launch and may still hold the previous thunk (the
+        # pipelined update hand-off keeps it across the next launch): a replaced thunk is retired, not freed,
+        # until no render thread can be running (Wait(), close()).
+        old = self._cbs.get(key)
+        if old is not None:
+            self._retired.append(old)
         if callback is None:
             self._cbs[key] = CALLBACK()
             setter(self._h, self._cbs[key], None)
             return
-        rows, width = self.rows, self.width
 
         def tramp(ptr, size, _user):
             n = size // 4
             img = np.ctypeslib.as_array(ptr, shape=(n,))
+            rows, width = self.rows, self.width            # read per call: Resize changes them
             callback(img.reshape(rows, width) if n == rows * width else img, size)
         self._cbs[key] = CALLBACK(tramp)       # keep alive
         setter(self._h, self._cbs[key], None)

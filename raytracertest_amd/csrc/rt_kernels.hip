@@ -269,7 +269,10 @@ static void launch_trace_fused(const TraceParams& p, int K, dim3 grid, size_t ld
 bool trace_can_fuse(bool filter, bool bin) { return filter && bin; }
 
 hipError_t launch_trace(const TraceParams& p, bool fma, bool filter, bool bin, int K, hipStream_t st) {
-  if (p.rows == 0 || p.W == 0 || p.samples == 0) return hipSuccess;
+  // samples == 0 is a real launch, as in the reference (TraceKernel with sampleCount 0: counts += 0,
+  // render += 0, RNG written back, Kernels.cuh:133-146): the fused clear / BGRA8 emit / list store of the
+  // launch still have to happen
+  if (p.rows == 0 || p.W == 0) return hipSuccess;
   const dim3 grid(cdiv(p.W, 32), cdiv(p.rows, 8));
   const size_t lds = trace_lds_bytes(p, bin);
   if (p.iters > 1u) {                // fused iterations: default (filtered, classified, un-instrumented) kernels only

@@ -109,11 +109,20 @@ struct Camera {
   }
 };
 
-struct EventPair { hipEvent_t a, b, c; uint32_t launches; bool split; };   // c: end of the lower half on stream_b
+struct EventPair { hipEvent_t a, b, c; uint32_t launches; bool split; uint64_t seq; };   // c: end of the lower half on stream_b
+
+struct Group;        // rt_multi.hpp: the tile gather of a frame sharded over several GPUs
+struct MultiState;   // rt_multi.hpp: the bands of a multi-device tracer
 
 }  // namespace
 
 struct rt_tracer {
+  // A handle is one of: a plain tracer (one device, the whole frame or one row band), a band tracer that
+  // joined a multi-process group (grp != null), or a multi-device tracer (mg != null: the fields below then
+  // describe the whole frame and hold camera, callbacks, render thread and error text; the device buffers
+  // live in the band tracers mg owns).
+  Group* grp = nullptr;
+  MultiState* mg = nullptr;
   // configuration
   int device = 0;
   uint32_t W = 0, H = 0;            // full image
@@ -137,19 +146,28 @@ struct rt_tracer {
   bool a_dirty = false;               // non-launch work on the primary stream that stream_b has not waited for yet
   bool split_launches = true;         // RT_MI355X_NO_SPLIT=1 turns it off
 
-  void join_b() {                     // primary stream waits for everything enqueued on stream_b
-    if (!b_dirty) return;
-    HIP_CHECK(hipEventRecord(join_event, stream_b));
-    HIP_CHECK(hipStreamWaitEvent(stream, join_event, 0));
-    b_dirty = false;
+  // The ordering state is shared by the render thread and by entry points that do not join it
+  // (rt_tracer_sync, rt_tracer_read_buffer, the device copies): order_mu serialises the dirty flags and the
+  // re-recording of the two shared events.
+  std::mutex order_mu;
+  hipStream_t main_stream() {         // primary stream, made to wait for everything enqueued on stream_b
+    std::lock_guard<std::mutex> lk(order_mu);
+    if (b_dirty) {
+      HIP_CHECK(hipEventRecord(join_event, stream_b));
+      HIP_CHECK(hipStreamWaitEvent(stream, join_event, 0));
+      b_dirty = false;
+    }
+    a_dirty = true;
+    return stream;
   }
-  hipStream_t main_stream() { join_b(); a_dirty = true; return stream; }
   void fork_b() {                     // stream_b waits for the non-launch work enqueued on the primary stream
+    std::lock_guard<std::mutex> lk(order_mu);
     if (!a_dirty) return;
     HIP_CHECK(hipEventRecord(fork_event, stream));
     HIP_CHECK(hipStreamWaitEvent(stream_b, fork_event, 0));
     a_dirty = false;
   }
+  void mark_b_dirty() { std::lock_guard<std::mutex> lk(order_mu); b_dirty = true; }
   float4* d_render = nullptr;
   uint32_t* d_counts = nullptr;
   uint32_t* d_image = nullptr;
@@ -182,6 +200,7 @@ struct rt_tracer {
   std::mutex time_mu;
   std::vector<EventPair> pending;
   std::vector<EventPair> free_events;
+  uint64_t next_event_seq = 0;
   double kernel_ms = 0.0;
   uint64_t kernel_launches = 0;
 
@@ -240,6 +259,20 @@ struct rt_tracer {
     HIP_CHECK(hipMemsetAsync(d_image, 0, n * sizeof(uint32_t), main_stream()));
     create_states();
     HIP_CHECK(hipStreamSynchronize(main_stream()));
+  }
+
+  // multi-device Resize: new frame size AND new band of it (scene, camera and options stay)
+  void reshape(uint32_t w, uint32_t h, uint32_t r0, uint32_t n) {
+    HIP_CHECK(hipStreamSynchronize(main_stream()));
+    release_buffers();
+    W = w; H = h; row0 = r0; rows = n;
+    list_key_valid = false;
+    create_buffers();
+  }
+
+  // the band's BGRA8 image to a gather buffer on the same device (paths that converted without a trace launch)
+  void copy_image_to(uint32_t* target) {
+    HIP_CHECK(hipMemcpyAsync(target, d_image, static_cast<size_t>(npix()) * sizeof(uint32_t), hipMemcpyDeviceToDevice, main_stream()));
   }
 
   rtk::TraceParams params(uint32_t samples) {
@@ -349,7 +382,7 @@ struct rt_tracer {
         HIP_CHECK(rtk::launch_trace(half[h], fma, filter, bin, K, st[h]));
       }
       if (timed) { HIP_CHECK(hipEventRecord(e.b, stream)); HIP_CHECK(hipEventRecord(e.c, stream_b)); }
-      b_dirty = true;
+      mark_b_dirty();
     }
     if (!timed) return;
     const EventPair* wait_for = nullptr;
@@ -357,6 +390,10 @@ struct rt_tracer {
     size_t back = 2;
     {
       std::lock_guard<std::mutex> lk(time_mu);
+      // enqueue-only callers (rt_tracer_trace_enqueue / rt_tracer_launch*) never wait here: recycle what has
+      // finished meanwhile, so that a long enqueue loop without rt_tracer_sync does not grow `pending`
+      if (sync_after == 0) reap_finished_locked();
+      e.seq = next_event_seq++;
       pending.push_back(e);
       // flow control in units of sampled launches: with stride s the launch waited for is
       // max(s, sync_after) launches back, i.e. fewer than sync_after + s launches are in flight
@@ -384,11 +421,8 @@ struct rt_tracer {
     return q;
   }
 
-  // account and recycle the event pairs of finished launches, keeping the newest `keep_last`
-  void drain_events(size_t keep_last = 0) {
-    std::lock_guard<std::mutex> lk(time_mu);
-    if (pending.size() <= keep_last) return;
-    const size_t n_done = pending.size() - keep_last;
+  // account and recycle the oldest n_done pairs (their launches have finished); time_mu held
+  void recycle_locked(size_t n_done) {
     for (size_t i = 0; i < n_done; ++i) {
       EventPair& e = pending[i];
       float ms = 0.0f;
@@ -397,6 +431,27 @@ struct rt_tracer {
     }
     pending.erase(pending.begin(), pending.begin() + static_cast<std::ptrdiff_t>(n_done));
   }
+  // the event pairs of finished launches, keeping the newest `keep_last` (the caller knows they finished)
+  void drain_events(size_t keep_last = 0) {
+    std::lock_guard<std::mutex> lk(time_mu);
+    if (pending.size() > keep_last) recycle_locked(pending.size() - keep_last);
+  }
+  // only the pairs pushed before `seq_end` (a caller that synchronised the streams at that point: pairs the
+  // render thread has pushed since may still be in flight)
+  void drain_events_before(uint64_t seq_end) {
+    std::lock_guard<std::mutex> lk(time_mu);
+    size_t n = 0;
+    while (n < pending.size() && pending[n].seq < seq_end) ++n;
+    recycle_locked(n);
+  }
+  void reap_finished_locked() {        // oldest first, no waiting
+    size_t n = 0;
+    while (n < pending.size() && hipEventQuery(pending[n].b) == hipSuccess &&
+           (!pending[n].split || hipEventQuery(pending[n].c) == hipSuccess)) ++n;
+    (void)hipGetLastError();           // hipErrorNotReady is an answer, not a failure of the next launch
+    recycle_locked(n);
+  }
+  uint64_t event_seq_now() { std::lock_guard<std::mutex> lk(time_mu); return next_event_seq; }
 
   void clear_accumulators() {                                            // :242-243
     HIP_CHECK(hipMemsetAsync(d_render, 0, static_cast<size_t>(npix()) * sizeof(float4), main_stream()));
@@ -443,6 +498,7 @@ struct rt_tracer {
       if (d_tile_lists) (void)hipFree(d_tile_lists);
       d_tile_lists = nullptr; tile_lists_words = 0; list_key_valid = false;
       HIP_CHECK(hipMalloc(&d_tile_lists, words * sizeof(uint32_t)));
+      HIP_CHECK(hipMemsetAsync(d_tile_lists, 0, words * sizeof(uint32_t), main_stream()));   // count 0 everywhere until a launch stores
       tile_lists_words = words;
     }
     ListKey k;
@@ -512,6 +568,27 @@ struct rt_tracer {
   }
 
   static constexpr int kWindow = 4;
+
+  // Device-resident form of one Trace (rt_tracer_trace_enqueue): clear + iterationCount launches + conversion,
+  // all enqueued, no callbacks, no host synchronisation.  `target`: second BGRA8 destination of the emitting
+  // launch (the caller's mirror or a gather buffer), or null.
+  void trace_enqueue_body(uint32_t iterationCount, uint32_t samplesPerIteration, uint32_t* target) {
+    use_device();
+    if (iterationCount == 0) {
+      clear_accumulators();
+      convert();
+      if (target) copy_image_to(target);
+      return;
+    }
+    const uint32_t group = fused_iterations(samplesPerIteration);
+    for (uint32_t i = 0; i < iterationCount;) {
+      const uint32_t n = iterationCount - i < group ? iterationCount - i : group;
+      const bool last = i + n == iterationCount;
+      enqueue_trace_launch(samplesPerIteration, (i == 0 ? rtk::TRACE_ZERO_ACC : 0u) | (last ? rtk::TRACE_EMIT_IMAGE : 0u),
+                           0, n, last ? target : nullptr);
+      i += n;
+    }
+  }
 
   // RayTracerImpl::TraceFunct, RayTracerImpl.cu:236-315 (runs on the render thread)
   // How many consecutive iterations one launch may run (1 = no fusing): bounded so that a launch
@@ -596,20 +673,31 @@ struct rt_tracer {
   }
 };
 
+#include "rt_multi.hpp"
+
 namespace {
 
 size_t buffer_bytes(rt_tracer* t, int which) {
-  const size_t n = t->npix();
+  const size_t n = t->npix();          // (a multi-device tracer: W x H of the whole frame)
   switch (which) {
     case RT_BUF_RENDER: return n * sizeof(float4);
     case RT_BUF_COUNTS: return n * sizeof(uint32_t);
     case RT_BUF_IMAGE: return n * sizeof(uint32_t);
     case RT_BUF_RNG: return n * 6 * sizeof(uint32_t);
+    case RT_BUF_FRAME: {               // the gathered frame: on the root of a group only
+      const Group* g = t->mg ? &t->mg->group : t->grp;
+      return (g && g->has_root) ? g->frame_bytes() : 0;
+    }
     default: return 0;
   }
 }
 
 void* buffer_ptr(rt_tracer* t, int which) {
+  if (which == RT_BUF_FRAME || (t->mg && which == RT_BUF_IMAGE)) {
+    Group* g = t->mg ? &t->mg->group : t->grp;
+    return (g && g->has_root) ? g->d_frame[g->last_b < 0 ? 0 : g->last_b] : nullptr;
+  }
+  if (t->mg) return nullptr;           // per-band buffers of a multi-device tracer: rt_tracer_read_buffer assembles them
   switch (which) {
     case RT_BUF_RENDER: return t->d_render;
     case RT_BUF_COUNTS: return t->d_counts;
@@ -659,6 +747,8 @@ int require_device(int device) {
 }
 
 }  // namespace
+
+#include "rt_multi_api.hpp"
 
 extern "C" {
 
@@ -780,6 +870,12 @@ void rt_tracer_destroy(rt_tracer* t) {                                   // RayT
   if (!t) return;
   t->stopped = true;
   if (t->thread.joinable()) t->thread.join();
+  if (t->mg) {                                                           // multi-device: the bands own the device state
+    multi_destroy(t);
+    delete t;
+    return;
+  }
+  member_leave(t);
   (void)hipSetDevice(t->device);
   if (t->stream_b) (void)hipStreamSynchronize(t->stream_b);
   if (t->stream) (void)hipStreamSynchronize(t->stream);
@@ -808,8 +904,9 @@ int rt_tracer_trace(rt_tracer* t, uint32_t iterationCount, uint32_t samplesPerIt
   return guarded(t, [&] {
     t->cancel_and_join();                                                // :72-77
     t->completed = false;
-    t->thread = std::thread(&rt_tracer::trace_funct, t, iterationCount, samplesPerIteration,
-                            updateInterval);                             // :80-85
+    if (t->mg) t->thread = std::thread(multi_trace_funct, t, iterationCount, samplesPerIteration, updateInterval);
+    else t->thread = std::thread(&rt_tracer::trace_funct, t, iterationCount, samplesPerIteration,
+                                 updateInterval);                        // :80-85
   });
 }
 
@@ -830,6 +927,8 @@ int rt_tracer_resize(rt_tracer* t, const uint32_t size[2]) {             // :94-
   std::lock_guard<std::mutex> lk(t->api_mu);
   return guarded(t, [&] {
     t->cancel_and_join();
+    if (t->mg) { multi_resize(t, size[0], size[1]); return; }
+    if (t->grp) throw HipFail{"Resize: the tracer is a member of a multi-process group (leave and re-join with the new bands)"};
     t->use_device();
     HIP_CHECK(hipStreamSynchronize(t->main_stream()));
     t->release_buffers();
@@ -867,6 +966,16 @@ static int upload_scene_impl(rt_tracer* t, const rt_float4* hostData, size_t cou
     return RT_ERR_INVALID;
   }
   std::lock_guard<std::mutex> lk(t->api_mu);
+  if (t->mg) {                                                           // the scene is replicated on every device
+    int rc = guarded(t, [&] { t->cancel_and_join(); multi_sync_all(t); });
+    for (rt_tracer* b : t->mg->bands) {
+      if (rc != RT_OK) break;
+      rc = upload_scene_impl(b, hostData, count, edges);
+      if (rc != RT_OK) t->set_error(b->last_error);
+    }
+    if (rc == RT_OK) { t->n_tris = static_cast<uint32_t>(count / 3); t->scene_generation++; }
+    return rc;
+  }
   return guarded(t, [&] {
     t->cancel_and_join();
     t->use_device();
@@ -920,6 +1029,16 @@ void rt_unpack_normal(float packed, float n[3]) {
 int rt_tracer_upload_spheres(rt_tracer* t, const rt_float4* spheres, size_t count) {
   if (!t || (count && !spheres)) return RT_ERR_INVALID;
   std::lock_guard<std::mutex> lk(t->api_mu);
+  if (t->mg) {
+    int rc = guarded(t, [&] { t->cancel_and_join(); multi_sync_all(t); });
+    for (rt_tracer* b : t->mg->bands) {
+      if (rc != RT_OK) break;
+      rc = rt_tracer_upload_spheres(b, spheres, count);
+      if (rc != RT_OK) t->set_error(b->last_error);
+    }
+    if (rc == RT_OK) t->n_spheres = static_cast<uint32_t>(count);
+    return rc;
+  }
   return guarded(t, [&] {
     t->cancel_and_join();
     t->use_device();
@@ -950,8 +1069,14 @@ int rt_tracer_set_seed(rt_tracer* t, uint64_t seed) {
   std::lock_guard<std::mutex> lk(t->api_mu);
   return guarded(t, [&] {
     t->cancel_and_join();
-    t->use_device();
     t->seed = seed;
+    if (t->mg) {
+      t->mg->opt.seed = seed;
+      for (rt_tracer* b : t->mg->bands)
+        if (rt_tracer_set_seed(b, seed) != RT_OK) throw HipFail{b->last_error};
+      return;
+    }
+    t->use_device();
     t->create_states();
     HIP_CHECK(hipStreamSynchronize(t->main_stream()));
   });
@@ -962,20 +1087,16 @@ int rt_tracer_trace_enqueue(rt_tracer* t, uint32_t iterationCount, uint32_t samp
   std::lock_guard<std::mutex> lk(t->api_mu);
   return guarded(t, [&] {
     t->cancel_and_join();
-    t->use_device();
-    if (iterationCount == 0) {
-      t->clear_accumulators();
-      t->convert();
+    if (t->mg) { multi_trace_enqueue(t, iterationCount, samplesPerIteration); return; }
+    if (t->grp) {                                                        // member of a multi-process group: trace, then the gather
+      const size_t k = member_band_index(t);
+      const int b = t->grp->begin_frame();
+      t->trace_enqueue_body(iterationCount, samplesPerIteration, t->grp->tile_target(k, b));
+      t->grp->tile_written(k);
+      t->grp->gather(b);
+      return;
     }
-    const uint32_t group = t->fused_iterations(samplesPerIteration);
-    for (uint32_t i = 0; i < iterationCount;) {
-      const uint32_t n = iterationCount - i < group ? iterationCount - i : group;
-      t->enqueue_trace_launch(samplesPerIteration,
-                              (i == 0 ? rtk::TRACE_ZERO_ACC : 0u) |
-                                  (i + n == iterationCount ? rtk::TRACE_EMIT_IMAGE : 0u),
-                              0, n, i + n == iterationCount ? t->image_mirror : nullptr);
-      i += n;
-    }
+    t->trace_enqueue_body(iterationCount, samplesPerIteration, t->image_mirror);
   });
 }
 
@@ -983,6 +1104,7 @@ int rt_tracer_set_list_reuse(rt_tracer* t, int across_traces) {
   if (!t) return RT_ERR_INVALID;
   std::lock_guard<std::mutex> lk(t->api_mu);
   t->cancel_and_join();
+  if (t->mg) for (rt_tracer* b : t->mg->bands) (void)rt_tracer_set_list_reuse(b, across_traces);
   t->reuse_across_traces = across_traces != 0;
   t->list_key_valid = false;
   return RT_OK;
@@ -991,43 +1113,64 @@ int rt_tracer_set_list_reuse(rt_tracer* t, int across_traces) {
 int rt_tracer_set_image_mirror(rt_tracer* t, void* device_visible_image) {
   if (!t) return RT_ERR_INVALID;
   std::lock_guard<std::mutex> lk(t->api_mu);
+  if (t->mg || t->grp) { t->set_error("rt_tracer_set_image_mirror: the gather owns the second image target of a sharded frame"); return RT_ERR_STATE; }
   t->image_mirror = static_cast<uint32_t*>(device_visible_image);
   return RT_OK;
 }
 
 int rt_tracer_fused_iterations(rt_tracer* t, uint32_t samples) {
+  if (t && t->mg) return static_cast<int>(t->mg->bands[0]->fused_iterations(samples));
   return t ? static_cast<int>(t->fused_iterations(samples)) : 0;
+}
+
+// one launch of rt_tracer_launch / rt_tracer_launch_iterations on any kind of handle
+static void launch_impl(rt_tracer* t, uint32_t samples, uint32_t iterations, bool clear_first, bool emit) {
+  t->cancel_and_join();
+  if (t->mg) { multi_launch(t, samples, iterations, clear_first, emit); return; }
+  t->use_device();
+  const uint32_t flags = (clear_first ? rtk::TRACE_ZERO_ACC : 0u) | (emit ? rtk::TRACE_EMIT_IMAGE : 0u);
+  if (t->grp && emit) {                                                  // member of a multi-process group: the tile travels
+    const size_t k = member_band_index(t);
+    const int b = t->grp->begin_frame();
+    t->enqueue_trace_launch(samples, flags, 0, iterations, t->grp->tile_target(k, b));
+    t->grp->tile_written(k);
+    t->grp->gather(b);
+    return;
+  }
+  t->enqueue_trace_launch(samples, flags, 0, iterations, emit ? t->image_mirror : nullptr);
 }
 
 int rt_tracer_launch_iterations(rt_tracer* t, uint32_t samples, uint32_t iterations, int clear_first, int emit_image) {
   if (!t || iterations == 0u) return RT_ERR_INVALID;
-  if (iterations > t->fused_iterations(samples)) {
+  if (iterations > static_cast<uint32_t>(rt_tracer_fused_iterations(t, samples))) {
     t->set_error(fmt("rt_tracer_launch_iterations: %u iterations of %u samples exceed rt_tracer_fused_iterations", iterations, samples));
     return RT_ERR_INVALID;
   }
   std::lock_guard<std::mutex> lk(t->api_mu);
-  return guarded(t, [&] {
-    t->cancel_and_join();
-    t->use_device();
-    t->enqueue_trace_launch(samples, (clear_first ? rtk::TRACE_ZERO_ACC : 0u) | (emit_image ? rtk::TRACE_EMIT_IMAGE : 0u),
-                            0, iterations, emit_image ? t->image_mirror : nullptr);
-  });
+  return guarded(t, [&] { launch_impl(t, samples, iterations, clear_first != 0, emit_image != 0); });
 }
 
 int rt_tracer_launch(rt_tracer* t, uint32_t samples, int clear_first, int emit_image) {
   if (!t) return RT_ERR_INVALID;
   std::lock_guard<std::mutex> lk(t->api_mu);
-  return guarded(t, [&] {
-    t->cancel_and_join();
-    t->use_device();
-    t->enqueue_trace_launch(samples, (clear_first ? rtk::TRACE_ZERO_ACC : 0u) | (emit_image ? rtk::TRACE_EMIT_IMAGE : 0u),
-                            0, 1, emit_image ? t->image_mirror : nullptr);
-  });
+  return guarded(t, [&] { launch_impl(t, samples, 1u, clear_first != 0, emit_image != 0); });
 }
 
 int rt_tracer_trace_stats(rt_tracer* t, uint32_t samples, uint64_t out[16]) {
   if (!t || !out) return RT_ERR_INVALID;
   std::lock_guard<std::mutex> lk(t->api_mu);
+  if (t->mg) {                                                           // sums over the bands
+    memset(out, 0, 16 * sizeof(uint64_t));
+    t->cancel_and_join();
+    multi_push_camera(t);
+    for (rt_tracer* b : t->mg->bands) {
+      uint64_t part[16];
+      const int rc = rt_tracer_trace_stats(b, samples, part);
+      if (rc != RT_OK) { t->set_error(b->last_error); return rc; }
+      for (int i = 0; i < 16; ++i) out[i] += part[i];
+    }
+    return RT_OK;
+  }
   return guarded(t, [&] {
     t->cancel_and_join();
     t->use_device();
@@ -1046,15 +1189,23 @@ int rt_tracer_trace_stats(rt_tracer* t, uint32_t samples, uint64_t out[16]) {
 
 int rt_tracer_sync(rt_tracer* t) {
   if (!t) return RT_ERR_INVALID;
+  if (t->mg) return guarded(t, [&] { multi_sync_all(t); });
   return guarded(t, [&] {
     t->use_device();
+    const uint64_t seen = t->event_seq_now();        // launches enqueued so far; a running render thread may add more
     HIP_CHECK(hipStreamSynchronize(t->main_stream()));
-    t->drain_events();
+    t->drain_events_before(seen);
+    if (t->grp) t->grp->sync();
   });
 }
 
 int rt_tracer_kernel_time(rt_tracer* t, double* total_ms, uint64_t* launches, int reset_after) {
   if (!t) return RT_ERR_INVALID;
+  if (t->mg) {                                                           // of the first band; reset applies to every band
+    const int rc = rt_tracer_kernel_time(t->mg->bands[0], total_ms, launches, reset_after);
+    if (reset_after) for (size_t k = 1; k < t->mg->bands.size(); ++k) (void)rt_tracer_kernel_time(t->mg->bands[k], nullptr, nullptr, 1);
+    return rc;
+  }
   std::lock_guard<std::mutex> lk(t->time_mu);
   if (total_ms) *total_ms = t->kernel_ms;
   if (launches) *launches = t->kernel_launches;
@@ -1066,18 +1217,30 @@ size_t rt_tracer_buffer_bytes(rt_tracer* t, int which) { return t ? buffer_bytes
 void* rt_tracer_device_pointer(rt_tracer* t, int which) { return t ? buffer_ptr(t, which) : nullptr; }
 
 int rt_tracer_read_buffer(rt_tracer* t, int which, void* dst, size_t bytes) {
-  if (!t || !dst || buffer_ptr(t, which) == nullptr || bytes > buffer_bytes(t, which)) return RT_ERR_INVALID;
+  if (!t || !dst) return RT_ERR_INVALID;
+  if (t->mg) {
+    if (bytes > buffer_bytes(t, which) || buffer_bytes(t, which) == 0) return RT_ERR_INVALID;
+    return guarded(t, [&] { multi_read_buffer(t, which, dst, bytes); });
+  }
+  if (buffer_ptr(t, which) == nullptr || bytes > buffer_bytes(t, which)) return RT_ERR_INVALID;
   return guarded(t, [&] {
     t->use_device();
     HIP_CHECK(hipStreamSynchronize(t->main_stream()));
+    if (t->grp) t->grp->sync();
     HIP_CHECK(hipMemcpy(dst, buffer_ptr(t, which), bytes, hipMemcpyDeviceToHost));
   });
 }
 
 int rt_tracer_copy_buffer_to_device(rt_tracer* t, int which, void* dst_device, size_t bytes) {
   if (!t || !dst_device || buffer_ptr(t, which) == nullptr || bytes > buffer_bytes(t, which)) return RT_ERR_INVALID;
+  if (t->mg) return guarded(t, [&] {                                      // the gathered frame, from the root device
+    multi_sync_all(t);
+    HIP_CHECK(hipSetDevice(t->mg->group.local[0].device));
+    HIP_CHECK(hipMemcpy(dst_device, buffer_ptr(t, which), bytes, hipMemcpyDeviceToDevice));
+  });
   return guarded(t, [&] {
     t->use_device();
+    if (t->grp && which == RT_BUF_FRAME) t->grp->sync();
     HIP_CHECK(hipMemcpyAsync(dst_device, buffer_ptr(t, which), bytes, hipMemcpyDeviceToDevice, t->main_stream()));
     HIP_CHECK(hipStreamSynchronize(t->main_stream()));
   });
@@ -1085,20 +1248,91 @@ int rt_tracer_copy_buffer_to_device(rt_tracer* t, int which, void* dst_device, s
 
 int rt_tracer_copy_buffer_to_device_async(rt_tracer* t, int which, void* dst_device, size_t bytes) {
   if (!t || !dst_device || buffer_ptr(t, which) == nullptr || bytes > buffer_bytes(t, which)) return RT_ERR_INVALID;
+  if (t->mg || which == RT_BUF_FRAME) { t->set_error("rt_tracer_copy_buffer_to_device_async: per-stream copies are for plain tracers' own buffers"); return RT_ERR_STATE; }
   return guarded(t, [&] {
     t->use_device();
     HIP_CHECK(hipMemcpyAsync(dst_device, buffer_ptr(t, which), bytes, hipMemcpyDeviceToDevice, t->main_stream()));
   });
 }
 
-void* rt_tracer_stream(rt_tracer* t) { return t ? static_cast<void*>(t->stream) : nullptr; }
-void* rt_tracer_stream_b(rt_tracer* t) { return t ? static_cast<void*>(t->stream_b) : nullptr; }
+void* rt_tracer_stream(rt_tracer* t) { return (t && !t->mg) ? static_cast<void*>(t->stream) : nullptr; }
+void* rt_tracer_stream_b(rt_tracer* t) { return (t && !t->mg) ? static_cast<void*>(t->stream_b) : nullptr; }
 
 int rt_tracer_info(rt_tracer* t, uint32_t out[8]) {
   if (!t || !out) return RT_ERR_INVALID;
+  if (t->mg) {                                                           // launch geometry of the first band, sizes of the frame
+    (void)rt_tracer_info(t->mg->bands[0], out);
+    out[3] = (t->W + 31) / 32; out[4] = (t->H + 7) / 8;
+    out[7] = static_cast<uint32_t>(t->device);
+    return RT_OK;
+  }
   out[0] = t->last_k; out[1] = t->last_chunk; out[2] = t->last_lds;
   out[3] = (t->W + 31) / 32; out[4] = (t->rows + 7) / 8;
   out[5] = t->n_tris; out[6] = t->n_spheres; out[7] = static_cast<uint32_t>(t->device);
+  return RT_OK;
+}
+
+// ---- a frame sharded over several GPUs ------------------------------------------------------
+
+int rt_tracer_create_multi(const uint32_t imageSize[2], const float cameraPosition[3], const float cameraAngles[2],
+                           float fov, float focalLength, float aperture, const rt_options* options,
+                           const int32_t* devices, uint32_t n_bands, rt_tracer** out) {
+  return multi_create(imageSize, cameraPosition, cameraAngles, fov, focalLength, aperture, options, devices, n_bands, out);
+}
+
+int rt_group_unique_id(uint8_t id[RT_GROUP_ID_BYTES]) {
+  if (!id) return RT_ERR_INVALID;
+  return guarded(nullptr, [&] {
+    ncclUniqueId uid;
+    RCCL_CHECK(need_rccl().GetUniqueId(&uid));
+    memcpy(id, uid.internal, RT_GROUP_ID_BYTES);
+  });
+}
+
+int rt_tracer_join_group(rt_tracer* t, uint32_t n_ranks, uint32_t rank, const uint8_t id[RT_GROUP_ID_BYTES]) {
+  if (!t || t->mg || n_ranks == 0u || rank >= n_ranks || (!id && n_ranks > 1u)) return RT_ERR_INVALID;
+  static const uint8_t zero_id[RT_GROUP_ID_BYTES] = {0};
+  std::lock_guard<std::mutex> lk(t->api_mu);
+  return guarded(t, [&] {
+    t->cancel_and_join();
+    member_join(t, n_ranks, rank, id ? id : zero_id);
+  });
+}
+
+int rt_tracer_leave_group(rt_tracer* t) {
+  if (!t || t->mg) return RT_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(t->api_mu);
+  return guarded(t, [&] {
+    t->cancel_and_join();
+    member_leave(t);
+  });
+}
+
+int rt_tracer_gather_time(rt_tracer* t, double* total_ms, uint64_t* gathers, int reset_after) {
+  if (!t) return RT_ERR_INVALID;
+  Group* g = t->mg ? &t->mg->group : t->grp;
+  if (total_ms) *total_ms = g ? g->gather_ms : 0.0;
+  if (gathers) *gathers = g ? g->gathers : 0u;
+  if (g && reset_after) { g->gather_ms = 0.0; g->gathers = 0; }
+  return RT_OK;
+}
+
+int rt_tracer_band_count(rt_tracer* t) {
+  if (!t) return 0;
+  return t->mg ? static_cast<int>(t->mg->bands.size()) : 1;
+}
+
+int rt_tracer_band_info(rt_tracer* t, uint32_t band, uint32_t out[4]) {
+  if (!t || !out) return RT_ERR_INVALID;
+  if (t->mg) {
+    if (band >= t->mg->bands.size()) return RT_ERR_INVALID;
+    const GroupBand& b = t->mg->group.bands[band];
+    out[0] = static_cast<uint32_t>(t->mg->band_device[band]); out[1] = b.row0; out[2] = b.rows; out[3] = static_cast<uint32_t>(b.rank);
+    return RT_OK;
+  }
+  if (band != 0u) return RT_ERR_INVALID;
+  out[0] = static_cast<uint32_t>(t->device); out[1] = t->row0; out[2] = t->rows;
+  out[3] = t->grp ? static_cast<uint32_t>(t->grp->local[0].rank) : 0u;
   return RT_OK;
 }
 
@@ -1227,6 +1461,7 @@ int rt_dbg_uniform(int device, uint32_t n, uint32_t m, uint32_t* states, float* 
 
 int rt_dbg_get_ray(rt_tracer* t, uint32_t n, const uint32_t* pixels, uint32_t* states, float* rays) {
   if (!t) return RT_ERR_INVALID;
+  if (t->mg) { multi_push_camera(t); return rt_dbg_get_ray(t->mg->bands[0], n, pixels, states, rays); }   // the camera of the whole frame
   return guarded(t, [&] {
     t->use_device();
     rtk::TraceParams p = t->params(1);

@@ -3,6 +3,7 @@
 // pytest side parses: update/finished counts, image size, an FNV-1a hash of the final image.
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <functional>
 #include <memory>
 #include <vector>
@@ -31,8 +32,16 @@ int main(int argc, char** argv) {
   const math::uvec2 imageSize(38, 21);                       // App.cpp:13
   const math::vec3 cameraPosition(0.0f, 0.0f, 0.0f);
   const math::vec2 cameraAngles(0.0f, 0.0f);
+  const int bands = argc > 2 ? atoi(argv[2]) : 0;             // > 0: the frame in `bands` row bands, spread over the devices
   Frame f;
-  f.mRayTracer = std::make_unique<rt::RayTracer>(imageSize, cameraPosition, cameraAngles, 70.0f, 10.0f, 4.0f);
+  if (bands > 0) {
+    const int n_dev = rt_device_count() > 0 ? rt_device_count() : 1;
+    std::vector<int> devices;
+    for (int k = 0; k < bands; ++k) devices.push_back(k % n_dev);
+    f.mRayTracer = std::make_unique<rt::RayTracer>(imageSize, cameraPosition, cameraAngles, 70.0f, 10.0f, 4.0f, devices);
+  } else {
+    f.mRayTracer = std::make_unique<rt::RayTracer>(imageSize, cameraPosition, cameraAngles, 70.0f, 10.0f, 4.0f);
+  }
   if (!f.mRayTracer->Valid()) { std::printf("CREATE_FAILED %s\n", f.mRayTracer->LastError().c_str()); return 2; }
   f.mRayTracer->SetSeed(seed);
   f.mRayTracer->SetUpdateCallback(std::bind(&Frame::TracerUpdateCallback, &f, std::placeholders::_1, std::placeholders::_2));

@@ -69,6 +69,8 @@ FRAMES = {
     "uvsphere_smooth_96x64": dict(W=96, H=64, scene="uvsphere", it=2, spp=4, fov=40.0, focal=4.0, aperture=0.1,
                                   edges=True, smooth=True, nearest=True),
     "C4_band4": dict(W=3840, H=2160, row0=1078, rows=4, scene="rand10k", it=1, spp=64, fov=70.0, focal=3.0, aperture=0.05),
+    # BASELINE configs[4]: the C4 scene at 256 spp (one launch), same four rows of the 3840x2160 frame
+    "C5_band4": dict(W=3840, H=2160, row0=1078, rows=4, scene="rand10k", it=1, spp=256, fov=70.0, focal=3.0, aperture=0.05),
 }
 
 
@@ -105,7 +107,7 @@ def frames(only=None):
     for name, spec in FRAMES.items():
         if only and name not in only:
             continue
-        modes = (1, 0) if name not in ("C4_band4",) else (1,)
+        modes = (1, 0) if name not in ("C4_band4", "C5_band4") else (1,)
         for contract in modes:
             key = "%s/%s" % (name, "fma" if contract else "strict")
             o = render(spec, contract)

@@ -29,11 +29,14 @@ def test_cpp_api_compiles_and_fails_loudly_without_gpu(tmp_path):
 
 
 @pytest.mark.gpu
-def test_cpp_driver_matches_python_host_mirror(tmp_path):
+@pytest.mark.parametrize("bands", [0, 8])
+def test_cpp_driver_matches_python_host_mirror(tmp_path, bands):
+    """bands = 8: the same caller through the device-list constructor (rt_tracer_create_multi): the frame in 8 row
+    bands, same callback cadence (ONE callback per update with the whole frame), same image."""
     import raytracertest_amd as R
     from raytracertest_amd import scenes
     exe = build_driver(tmp_path)
-    out = subprocess.run([exe, "5"], capture_output=True, text=True, timeout=120)
+    out = subprocess.run([exe, "5", str(bands)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     m = re.search(r"RESULT done=(\d) updates=(\d+) finished=(\d+) size=(\d+) hash=(\d+) count0=(\d+)", out.stdout)
     assert m, out.stdout
