@@ -1,32 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- Mray/s of the trace path on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W            (any N: ONE process; for N > 1 the library shards the
+                                                            frame over the devices itself, rt_tracer_create_multi)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W
+         --master-port P bench.py --gpus N --steps K --warmup W     (one process per GPU, rt_tracer_join_group)
 
 A "step" is one complete Trace pass of the hot path on device-resident buffers: clear the
-accumulators, ONE trace-kernel launch of `samples` spp over the rank's rows, the BGRA8
-conversion and -- for N > 1 -- the RCCL gather of the finished tiles to rank 0
-(RayTracerImpl.cu:236-315 without the GUI hand-off).  Workload at N=1: BASELINE.json
-configs[2] = C3 (Cornell-box 32 triangles, thin-lens DoF, 1920x1080, 16 spp), the
-configuration the metric is quoted on.  For N > 1 the frame grows to 1920 x (1080*N) and
-every rank owns one 1080-row band: per-GPU work is fixed ("weak"), no data-path collective
-except the tile gather the north star names.  --config C5 is BASELINE.json configs[4]: the
-10k-triangle scene at 3840x2160x256 spp as ONE frame split into N row bands ("strong").
+accumulators, ONE trace-kernel launch of `samples` spp over every band (fused clear and BGRA8
+conversion) and -- for N > 1 -- the RCCL gather of the finished tiles to the root device
+(RayTracerImpl.cu:236-315 without the GUI hand-off).  Workload at N=1: BASELINE.json configs[2] = C3
+(Cornell-box 32 triangles, thin-lens DoF, 1920x1080, 16 spp), the configuration the metric is quoted
+on.  For N > 1 the headline record keeps per-GPU work fixed ("weak": the frame grows to 1920 x (1080*N),
+one 1080-row band per GPU) and the same line carries a second record, `c5_strong`: BASELINE.json
+configs[4], the 10k-triangle scene at 3840x2160x256 spp as ONE frame in N row bands.  If the box has
+fewer devices than N (a 1-GPU box), the single-process form places the bands round-robin on what is
+there and says so (`config.devices`).
 
 Prints ONE JSON line on rank 0 with
-  roofline      HBM: algorithmic bytes per launch / live HIP-event kernel time vs 8 TB/s
-                (contractual bound; the path is VALU-bound by construction)
-  valu          the binding bound: algorithmic fp32 flops (by the reference's exit points,
-                counted by an instrumented launch) vs the 157.3 TFLOP/s spec peak and vs
-                the lane-FMA rate this device sustains (calibrated live); valu.issue = the
-                VALU instructions the kernel really issued (PMC pass, profiles/valu_issue.json)
-                per second vs the calibrated wave64 instruction rate
+  roofline      HBM: algorithmic bytes per launch / live HIP-event kernel time vs 8 TB/s (contractual
+                bound), frac_wall = the same bytes / wall time per step, and the R = 48 accounting beside it
+  valu          the binding bound: VALU instructions issued per launch (PMC pass, stamped with the kernel
+                source hash: null + stale when the loaded library is a different build) against the wave64
+                issue rate this device sustains (calibrated live); `algorithmic` = the reference's
+                full-scan flops for context (a ratio, not a utilisation)
+  gather_ms     N > 1: device time of one tile gather on the root's gather stream
   warm_lists    NOT the headline: the same steps with the library's default list reuse across Traces
-                (the headline steps rebuild their tile candidate lists every time)
-  cpu_baseline  the oracle (scalar CPU port of the reference kernel) timed on this box's
-                cores on a bounded sample of the same workload
+  cpu_baseline  the oracle (scalar CPU port of the reference kernel) timed on this box's cores, N = 1 only
 """
 import argparse
 import json
@@ -44,11 +44,16 @@ RNG_STATE_BYTES = 24           # persisted per pixel: d + v[5] (the reference's 
 FLOP_BY_EXIT = (20, 30, 46, 52)   # culled at det / rejected at u / at v / full
 FLOP_PER_RAY_SETUP = 100          # ray generation + shading, per ray
 
+WORKLOADS = {"C2": "C2: 1 sphere, pinhole, 512x512, 1 spp",
+             "C3": "C3: Cornell-box 32 triangles, thin-lens DoF, 1920x1080, 16 spp",
+             "C4": "C4: 10k random triangles, 3840x2160, 64 spp",
+             "C5": "C5: 10k random triangles, 3840x2160, 256 spp, one frame in row bands"}
 
-def algorithmic_bytes(width, rows, n_tris, n_spheres):
-    """per launch, W*H*(2*R + 32) + 48*N_tri + 16*N_sph; R = 24 here.
+
+def algorithmic_bytes(width, rows, n_tris, n_spheres, rng_bytes=RNG_STATE_BYTES):
+    """per launch, W*H*(2*R + 32) + 48*N_tri + 16*N_sph.
     32 = render-buffer RMW 12+12 + sample-count RMW 4+4."""
-    return width * rows * (2 * RNG_STATE_BYTES + 32) + 48 * n_tris + 16 * n_spheres
+    return width * rows * (2 * rng_bytes + 32) + 48 * n_tris + 16 * n_spheres
 
 
 def host_threads():
@@ -103,17 +108,51 @@ def cpu_baseline(cfg, tris, spheres, rows, threads):
                       % (rows, cfg["width"], H, row0, row0 + rows - 1, launches, cfg["samples"], rays, dt, dt * threads)}
 
 
+def timed_steps(job, steps, warmup):
+    """W untimed steps, then exactly K steps bracketed by (device drain + barrier) on both sides; MAX over ranks."""
+    for _ in range(warmup):
+        job.step()
+    job.finish()
+    job.tracer.KernelTime(reset=True)
+    job.tracer.GatherTime(reset=True)
+    job.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        job.step()
+    job.finish()
+    job.barrier()
+    elapsed = job.max_over_ranks(time.perf_counter() - t0)
+    kernel_ms, launches = job.tracer.KernelTime(reset=True)
+    gather_ms, gathers = job.tracer.GatherTime(reset=True)
+    return {"elapsed": elapsed, "kernel_ms": kernel_ms, "launches": launches, "gather_ms": gather_ms, "gathers": gathers}
+
+
+def stamped(path, config, kernel_hash):
+    """(entry, stale): the profiles/*.json entry for `config` if it was collected on THIS kernel build."""
+    try:
+        doc = json.load(open(path))
+    except (OSError, ValueError):
+        return None, False
+    entry = doc.get(config)
+    if not entry:
+        return None, False
+    if doc.get("kernel_source_hash") != kernel_hash:
+        return None, True
+    return entry, False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4", "C5"],
-                    help="C3 (default, the metric's configuration; weak scaling for --gpus N); C5 = the C4 scene at 256 spp, "
-                         "ONE 3840x2160 frame split into N row bands (strong scaling, BASELINE configs[4])")
+                    help="C3 (default, the metric's configuration; weak scaling for --gpus N, with a C5 strong-scaling record "
+                         "beside it); C5 = the C4 scene at 256 spp, ONE 3840x2160 frame in N row bands (BASELINE configs[4])")
     ap.add_argument("--cpu-rows", type=int, default=-1, help="rows of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-valu", action="store_true", help="skip the instrumented launch + VALU calibration")
     ap.add_argument("--no-warm", action="store_true", help="skip the extra warm_lists measurement (profiling runs: headline launches only)")
+    ap.add_argument("--no-c5", action="store_true", help="N > 1: skip the c5_strong record")
     ap.add_argument("--samples-in-flight", type=int, default=0)
     ap.add_argument("--lds-chunk", type=int, default=0)
     args = ap.parse_args()
@@ -125,39 +164,40 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
-        args.gpus = world
+    devices = None
+    if world > 1:
+        args.gpus = world                                  # one process per GPU: the launcher decides
+        if local_rank >= R.device_count():
+            sys.exit("bench.py: rank %d has no HIP device %d (one process per GPU needs %d devices; on a smaller box run "
+                     "`python bench.py --gpus %d` without a launcher)" % (rank, local_rank, world, world))
+    elif args.gpus > 1:                                    # one process, the library shards the frame over the devices
+        n_dev = R.device_count()
+        if n_dev < 1:
+            sys.exit("bench.py: no HIP device")
+        devices = [k % n_dev for k in range(args.gpus)]
+    n_parts = args.gpus
+    sharding = "single GPU" if n_parts == 1 else (
+        "one process per GPU (rt_tracer_join_group), RCCL gather of BGRA8 tiles to rank 0" if world > 1 else
+        "one process, %d row bands over %d device(s) (rt_tracer_create_multi), RCCL gather of BGRA8 tiles to the root device"
+        % (n_parts, len(set(devices))))
 
     cfg = dict(scenes.CONFIGS[args.config])
     tris, spheres = scenes.scene_for(args.config)
     n_tris = tris.shape[0] // 3
-
     weak = args.config != "C5"
-    job = RowBandJob(cfg, tris, spheres, world=world, rank=rank, local_rank=local_rank, weak=weak,
+
+    job = RowBandJob(cfg, tris, spheres, world=world, rank=rank, local_rank=local_rank, weak=weak, devices=devices,
                      samples_in_flight=args.samples_in_flight, lds_chunk=args.lds_chunk)
     # Headline: every step is a from-scratch Trace pass -- the tile candidate lists (a camera-dependent
     # acceleration structure the library keeps between Traces by default) are NOT carried from step to step.
     job.tracer.SetListReuse(False)
-    for _ in range(args.warmup):
-        job.step()
-    job.finish()
-    job.tracer.KernelTime(reset=True)
-
-    job.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        job.step()
-    job.finish()
-    job.barrier()
-    elapsed = job.max_over_ranks(time.perf_counter() - t0)
-
-    kernel_ms, launches = job.tracer.KernelTime(reset=True)
+    res = timed_steps(job, args.steps, args.warmup)
+    elapsed, kernel_ms, launches = res["elapsed"], res["kernel_ms"], res["launches"]
+    bands = job.tracer.Bands()
+    band0_rows = bands[0]["rows"]
 
     warm = None
-    if world == 1 and args.config in ("C2", "C3") and not args.no_warm:
+    if n_parts == 1 and args.config in ("C2", "C3") and not args.no_warm:
         # the library's default behaviour for repeated Traces of an unchanged view: lists built once, then reused
         job.tracer.SetListReuse(True)
         for _ in range(max(args.warmup, 2)):
@@ -175,47 +215,87 @@ def main():
                 "note": "NOT the headline: same steps with the tile candidate lists kept between Traces (library default, "
                         "rt_tracer_set_list_reuse): classification and ray-family work happen once, results identical"}
         job.tracer.SetListReuse(False)
-    rays_per_gpu = cfg["width"] * job.rows * cfg["samples"] * cfg["iterations"]      # this rank's band
-    total_rays = cfg["width"] * cfg["height"] * (world if weak else 1) * cfg["samples"] * cfg["iterations"]
+    launch_info = job.tracer.Info()
+    version = R.load_library().rt_version().decode()
+    kernel_hash = version.split("kernels=")[-1].rstrip(")") if "kernels=" in version else None
+    job.close(destroy_group=False)
+
+    # N > 1: the strong-scaling record of BASELINE configs[4] beside the weak headline
+    c5 = None
+    if n_parts > 1 and args.config == "C3" and not args.no_c5:
+        cfg5 = dict(scenes.CONFIGS["C5"])
+        tris5, sph5 = scenes.scene_for("C5")
+        job5 = RowBandJob(cfg5, tris5, sph5, world=world, rank=rank, local_rank=local_rank, weak=False, devices=devices)
+        job5.tracer.SetListReuse(False)
+        steps5, warm5 = max(2, min(args.steps, 20)), max(1, min(args.warmup, 2))
+        r5 = timed_steps(job5, steps5, warm5)
+        rays5 = cfg5["width"] * cfg5["height"] * cfg5["samples"] * cfg5["iterations"]
+        c5 = {"workload": WORKLOADS["C5"], "scaling": "strong", "value": round(rays5 * steps5 / r5["elapsed"] / 1e6, 2), "unit": "Mray/s",
+              "steps": steps5, "warmup": warm5, "ms_per_step": round(r5["elapsed"] / steps5 * 1e3, 4),
+              "kernel_ms_band0": round(r5["kernel_ms"] / max(r5["launches"], 1), 4),
+              "gather_ms": round(r5["gather_ms"] / r5["gathers"], 4) if r5["gathers"] else 0.0,
+              "image": "%dx%d frame in %d row bands" % (cfg5["width"], cfg5["height"], n_parts)}
+        job5.close(destroy_group=False)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+    rays_band0 = cfg["width"] * band0_rows * cfg["samples"] * cfg["iterations"]
+    total_rays = cfg["width"] * cfg["height"] * (n_parts if weak else 1) * cfg["samples"] * cfg["iterations"]
     value = total_rays * args.steps / elapsed / 1e6
 
     if rank == 0:
         avg_kernel_s = kernel_ms / max(launches, 1) / 1e3
-        b_alg = algorithmic_bytes(cfg["width"], job.rows, n_tris, spheres.shape[0])        # rank 0's band
+        b_alg = algorithmic_bytes(cfg["width"], band0_rows, n_tris, spheres.shape[0])        # one GPU's band
+        b_alg48 = algorithmic_bytes(cfg["width"], band0_rows, n_tris, spheres.shape[0], 48)
         achieved = b_alg / avg_kernel_s / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(args.config, {}).get("bytes_per_launch")
+        step_s = elapsed / args.steps
+        traffic, traffic_stale = stamped(os.path.join(ROOT, "profiles", "hbm_traffic.json"), args.config, kernel_hash)
+        split = band0_rows >= 128 and os.environ.get("RT_MI355X_NO_SPLIT") != "1"
         out = {
             "metric": "Mray/s at %dx%dx%dspp" % (cfg["width"], cfg["height"], cfg["samples"]),
-            "value": round(value, 2), "unit": "Mray/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "value": round(value, 2), "unit": "Mray/s", "n_gpus": n_parts, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 5),
             "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": {"C2": "C2: 1 sphere, pinhole, 512x512, 1 spp",
-                                    "C3": "C3: Cornell-box 32 triangles, thin-lens DoF, 1920x1080, 16 spp",
-                                    "C4": "C4: 10k random triangles, 3840x2160, 64 spp",
-                                    "C5": "C5: 10k random triangles, 3840x2160, 256 spp, one frame in row bands"}[args.config],
+            "config": {"workload": WORKLOADS[args.config],
                        "image": "%dx%d per GPU (row band of a %dx%d frame)" % (
-                           cfg["width"], job.rows, cfg["width"], cfg["height"] * (world if weak else 1)),
+                           cfg["width"], band0_rows, cfg["width"], cfg["height"] * (n_parts if weak else 1)),
                        "triangles": n_tris, "spheres": int(spheres.shape[0]), "samples_per_launch": cfg["samples"],
-                       "launch": job.tracer.Info(), "math_mode": "fma", "rng_seed": cfg["seed"],
-                       "sharding": "row bands, RCCL gather of BGRA8 tiles to rank 0" if world > 1 else "single GPU"},
+                       "launch": launch_info, "math_mode": "fma", "rng_seed": cfg["seed"],
+                       "sharding": sharding, "library": version},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "frac_wall": round(b_alg / step_s / 1e9 / HBM_PEAK_GBS, 5),
+                         "traffic": traffic.get("bytes_per_launch") if traffic else None,
                          "kernel": "trace_kernel", "kernel_us": round(avg_kernel_s * 1e6, 2),
-                         "kernels_per_launch": 2 if job.rows >= 128 and os.environ.get("RT_MI355X_NO_SPLIT") != "1" else 1,
-                         "kernel_Mray_s": round(rays_per_gpu / avg_kernel_s / 1e6, 2),
-                         "algorithmic_bytes_per_launch": b_alg,
-                         "note": "contractual bound; the path is fp32-VALU-bound by construction "
-                                 "(SURVEY.md 0.5, BASELINE.md 2): see valu.  A launch runs as two half-frame kernels on two "
-                                 "streams that execute concurrently: kernel_us is the sampled duration of one of them (what "
-                                 "rocprofv3 lists per dispatch), achieved = the launch's algorithmic bytes / kernel_us"},
+                         "kernels_per_launch": 2 if split else 1,
+                         "kernel_Mray_s": round(rays_band0 / avg_kernel_s / 1e6, 2),
+                         "algorithmic_bytes_per_launch": b_alg, "rng_state_bytes": RNG_STATE_BYTES,
+                         "reference_layout_R48": {"algorithmic_bytes_per_launch": b_alg48,
+                                                  "frac": round(b_alg48 / avg_kernel_s / 1e9 / HBM_PEAK_GBS, 5),
+                                                  "note": "what the same kernel time would read with the reference's 48-byte curandState_t "
+                                                          "accounting (SURVEY 8d); those bytes are NOT moved: the build persists 24 B/pixel"},
+                         "note": "contractual bound; the path is fp32-VALU-issue-bound by construction (SURVEY.md 0.5, BASELINE.md 2): see "
+                                 "valu.  A launch runs as two half-frame kernels on two streams that execute concurrently "
+                                 "(profiles/r02_c3_overlap.csv): kernel_us is the sampled duration of one of them (what rocprofv3 lists per "
+                                 "dispatch), frac = the launch's algorithmic bytes / kernel_us / peak, frac_wall = the same bytes / "
+                                 "ms_per_step / peak (clear, both kernels, conversion, launch gaps: everything a step costs)"},
         }
+        if traffic_stale:
+            out["roofline"]["traffic_stale"] = True      # profiles/hbm_traffic.json belongs to another kernel build
+        if n_parts > 1:
+            out["config"]["devices"] = [b["device"] for b in bands] if bands and len(bands) > 1 else list(range(n_parts))
+            out["gather_ms"] = round(res["gather_ms"] / res["gathers"], 4) if res["gathers"] else 0.0
+            out["gather_note"] = ("device time of one gather on the root's gather stream (HIP events around the grouped ncclSend/ncclRecv; "
+                                  "includes waiting for the slowest peer's tile); it overlaps the next step's tracing.  0 with every band "
+                                  "on the root device: those tiles are written in place by the trace kernel")
+            if c5 is not None:
+                out["c5_strong"] = c5
         if warm is not None:
             out["warm_lists"] = warm
-        if not args.no_valu and world == 1 and args.config != "C5":      # (rank 0 must not fall behind its peers before the group is torn down)
+        if not args.no_valu and n_parts == 1 and args.config != "C5":
             # instrumented launch of the reference's own algorithm (every ray scans the whole list,
             # reference-order tests) on a scratch tracer: exit points per test
             g = R.RayTracer((cfg["width"], cfg["height"]), (0, 0, 0), cfg["angles"], cfg["fov"], cfg["focal"],
@@ -229,37 +309,31 @@ def main():
             g.close()
             exits = [st["exit_det"], st["exit_u"], st["exit_v"], st["exit_hit"]]
             scale = cfg["samples"] / st_samples
-            flop = scale * sum(f * e for f, e in zip(FLOP_BY_EXIT, exits)) + FLOP_PER_RAY_SETUP * rays_per_gpu
+            flop = scale * sum(f * e for f, e in zip(FLOP_BY_EXIT, exits)) + FLOP_PER_RAY_SETUP * rays_band0
             lane_fma, ghz = api.dbg_valu_peak(local_rank)
+            rate_peak = lane_fma / 64.0                      # wave64 VALU instructions per second, whole device
             tf = flop / avg_kernel_s / 1e12
-            out["valu"] = {"bound": "fp32 VALU", "achieved": round(tf, 2), "peak": VALU_PEAK_TFLOPS,
-                           "unit": "TFLOP/s", "frac": round(tf / VALU_PEAK_TFLOPS, 4),
-                           "attainable": round(2 * lane_fma / 1e12, 2), "frac_attainable": round(tf / (2 * lane_fma / 1e12), 4),
-                           "clock_ghz_under_load": round(ghz, 3),
-                           "tests_per_s": round(scale * sum(exits) / avg_kernel_s, 1),
-                           "exit_fractions": [round(e / max(sum(exits), 1), 4) for e in exits],
-                           "algorithmic_flop_per_launch": int(flop),
-                           "note": "ALGORITHMIC flops of the reference's full scan: every ray x every triangle priced by "
-                                   "the reference's exit point (20/30/46/52, FMA = 2) + 100 per ray.  The kernel skips "
-                                   "triangles its per-tile classification proves missed, so frac > what the VALU executes; "
-                                   "attainable = 2 x lane-FMA/s of an 8-chain fma loop at 8 waves/SIMD on this device"}
-            # what the VALU actually issued (PMC pass of the same command, profiles/valu_issue.json) against
-            # the issue rate the calibration loop reaches on this device: the kernel's real bound
-            issued = None
-            try:
-                issued = json.load(open(os.path.join(ROOT, "profiles", "valu_issue.json")))[args.config]
-            except (OSError, KeyError, ValueError):
-                pass
+            issued, issued_stale = stamped(os.path.join(ROOT, "profiles", "valu_issue.json"), args.config, kernel_hash)
+            valu = {"bound": "fp32 VALU issue", "unit": "Ginst/s (wave64)", "peak": round(rate_peak / 1e9, 2),
+                    "peak_note": "wave64 instruction rate of an 8-chain v_fma_f32 loop at 8 waves/SIMD on this device, measured now",
+                    "clock_ghz_under_load": round(ghz, 3), "achieved": None, "frac": None}
             if issued:
                 n_inst = issued["valu_wave_instructions_per_launch"]
-                rate_peak = lane_fma / 64.0                      # wave64 VALU instructions per second, whole device
-                out["valu"]["issue"] = {"valu_wave_instructions_per_launch": n_inst,
-                                        "lane_instructions_per_ray": round(n_inst * 64.0 / rays_per_gpu, 1),
-                                        "achieved_Ginst_s": round(n_inst / avg_kernel_s / 1e9, 2),
-                                        "attainable_Ginst_s": round(rate_peak / 1e9, 2),
-                                        "frac": round(n_inst / avg_kernel_s / rate_peak, 4),
-                                        "note": "SQ_INSTS_VALU per launch (rocprofv3 --pmc, own pass) / kernel time, against the "
-                                                "wave64 instruction rate of the fma calibration loop on this device"}
+                valu.update({"achieved": round(n_inst / avg_kernel_s / 1e9, 2), "frac": round(n_inst / avg_kernel_s / rate_peak, 4),
+                             "valu_wave_instructions_per_launch": n_inst,
+                             "lane_instructions_per_ray": round(n_inst * 64.0 / rays_band0, 1),
+                             "note": "SQ_INSTS_VALU per launch (rocprofv3 --pmc, own pass, same kernel build) / kernel time"})
+            elif issued_stale:
+                valu["stale"] = True                         # profiles/valu_issue.json belongs to another kernel build
+            valu["algorithmic"] = {
+                "full_scan_tflops_equivalent": round(tf, 2), "spec_peak_tflops": VALU_PEAK_TFLOPS,
+                "ratio_to_spec_peak": round(tf / VALU_PEAK_TFLOPS, 4),
+                "tests_per_s": round(scale * sum(exits) / avg_kernel_s, 1),
+                "exit_fractions": [round(e / max(sum(exits), 1), 4) for e in exits],
+                "algorithmic_flop_per_launch": int(flop),
+                "note": "NOT a utilisation: the flops of the reference's full scan (every ray x every triangle priced by its exit point, "
+                        "20/30/46/52, FMA = 2, + 100 per ray) divided by this kernel's time.  The kernel skips the triangles its per-tile "
+                        "classification proves missed, so the ratio may exceed 1"}
             g = R.RayTracer((cfg["width"], cfg["height"]), (0, 0, 0), cfg["angles"], cfg["fov"], cfg["focal"],
                             cfg["aperture"], seed=cfg["seed"], device=local_rank)
             if tris.shape[0]:
@@ -267,13 +341,13 @@ def main():
             sb = g.TraceStats(st_samples)
             g.close()
             waves = ((cfg["width"] + 7) // 8) * ((cfg["height"] + 7) // 8)
-            out["valu"]["binning"] = {"candidates_per_tile": round(sb["bin_candidates"] / max(sb["bin_rounds"], 1), 2),
-                                      "of_triangles": n_tris, "classification_rounds_per_tile": round(sb["bin_rounds"] / waves, 3)}
-        if world == 1 and args.cpu_rows != 0:
+            valu["binning"] = {"candidates_per_tile": round(sb["bin_candidates"] / max(sb["bin_rounds"], 1), 2),
+                               "of_triangles": n_tris, "classification_rounds_per_tile": round(sb["bin_rounds"] / waves, 3)}
+            out["valu"] = valu
+        if n_parts == 1 and args.cpu_rows != 0:
             rows = args.cpu_rows if args.cpu_rows > 0 else min(cfg["height"], {"C2": 512, "C3": 1080, "C4": 8, "C5": 2}[args.config])
             out["cpu_baseline"] = cpu_baseline(cfg, tris, spheres, rows, host_threads())
         print(json.dumps(out), flush=True)
-    job.close()
 
 
 if __name__ == "__main__":

@@ -752,7 +752,10 @@ int require_device(int device) {
 
 extern "C" {
 
-const char* rt_version(void) { return "rt_mi355x 0.1 (gfx950)"; }
+#ifndef RT_KERNEL_SOURCE_HASH
+#define RT_KERNEL_SOURCE_HASH "unknown"
+#endif
+const char* rt_version(void) { return "rt_mi355x 0.2 (gfx950, kernels=" RT_KERNEL_SOURCE_HASH ")"; }
 
 int rt_device_count(void) {
   int n = 0;

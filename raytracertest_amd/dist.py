@@ -1,34 +1,36 @@
-"""Row-band sharding of one frame across the GPUs of a node.
+"""Row-band sharding of one frame across the GPUs of a node, host side.
 
-One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo"
-on CPU for the tests).  Pixels are independent and every pixel's RNG stream is keyed by
-its GLOBAL index (subsequence = x + y*W, RayTracer/Random.cu:21-27), so the frame is
-invariant to the partition: rank g of G owns the contiguous rows [g*H/G, (g+1)*H/G) and
-traces them with no exchange at all.  The only collective is the gather of the finished
-BGRA8 tiles to rank 0 (the hand-off the reference does through its callback,
-RayTracerImpl.cu:287-305).  On the fully connected xGMI mesh every peer has its own link
-to the root, so the G-1 tile transfers run in parallel; a ring all-reduce would be the
-wrong primitive (nothing is reduced).
+Pixels are independent and every pixel's RNG stream is keyed by its GLOBAL index (subsequence =
+x + y*W, RayTracer/Random.cu:21-27), so the frame is invariant to the partition: band g of G owns
+the contiguous rows [g*H/G, (g+1)*H/G) and is traced with no exchange at all.  The only data
+movement is the hand-off the reference does through its callback (RayTracerImpl.cu:287-305): the
+finished BGRA8 tiles travel to the root.  That gather is NATIVE -- librt_mi355x calls RCCL itself
+(grouped ncclSend/ncclRecv over xGMI, csrc/rt_multi.hpp) on gather streams of its own, ordered
+behind the trace streams by events, double-buffered so that frame i is gathered while frame i+1 is
+traced.  Two ways to drive it:
 
-The gather of frame i runs on torch's stream while the tracer's own HIP stream already
-traces frame i+1 (two tile buffers, ordered with events through
-torch.cuda.ExternalStream): the host never blocks inside the loop.
+  * one process, several devices (`devices=[...]`): rt_tracer_create_multi -- the library owns the bands,
+    one host thread per device, the reference's API unchanged (what `python bench.py --gpus N` uses);
+  * one process per GPU (torch.distributed.run): every rank creates the tracer of its band and joins
+    the group (rt_tracer_join_group); the launcher's rendezvous only carries the 128-byte id and the
+    control-plane scalars (barrier, max, stop agreement) -- a gloo process group, no GPU tensors.
 
-PyTorch is plumbing here (process group, device tensors for the gather); the compute is
-the C-ABI library.
+PyTorch is plumbing here; the compute and the collective are the C-ABI library's.
 """
 import numpy as np
 
 
 def band_rows(height, world, rank):
-    """Rows [begin, begin+count) of rank `rank` of `world`: contiguous, balanced to one row."""
+    """Rows [begin, begin+count) of rank `rank` of `world`: contiguous, balanced to one row
+    (the same partition rt_tracer_create_multi / rt_tracer_join_group use)."""
     begin = (height * rank) // world
     end = (height * (rank + 1)) // world
     return begin, end - begin
 
 
 def gather_tiles(tile, world, rank, group=None, all_rows=None, out=None):
-    """Gather equal-or-ragged row tiles (torch tensors, (rows_i, W)) to rank 0.
+    """Gather equal-or-ragged row tiles (torch tensors, (rows_i, W)) to rank 0 through torch.distributed --
+    the exchange of the CPU tests (gloo); the GPU path gathers natively (see the module docstring).
 
     Returns the stacked (sum rows_i, W) tensor on rank 0, None elsewhere.  Ragged bands
     are padded to the tallest band for the collective and cropped afterwards.
@@ -65,8 +67,8 @@ def update_due(i, update_interval, have_callback=True):
 
 def progressive_trace(launch, tile, world, rank, iterations, samples, update_interval,
                       on_update=None, on_finished=None, stop_requested=None, all_reduce_max=None,
-                      have_update_callback=None, fuse=1):
-    """RayTracerImpl::TraceFunct (RayTracerImpl.cu:236-315) for a frame sharded in row bands.
+                      have_update_callback=None, fuse=1, gather=None):
+    """RayTracerImpl::TraceFunct (RayTracerImpl.cu:236-315) for a frame sharded in row bands over RANKS.
 
     Every rank runs the same iteration loop on its own band; at an update iteration and at
     the end the BGRA8 tiles are gathered to rank 0, which fires the callbacks with the whole
@@ -81,13 +83,17 @@ def progressive_trace(launch, tile, world, rank, iterations, samples, update_int
     agreement and one state round trip per group (RayTracer.Launch(iterations=n)).
 
       launch(samples, clear_first, emit_image[, n])  -> enqueue one launch on this rank's band
-      tile()                                    -> this rank's finished (rows, W) BGRA8 tensor
+      tile()                                    -> this rank's finished tile, handed to `gather`
+      gather(tile) -> frame on rank 0 / None    -> default: gather_tiles over torch.distributed
       all_reduce_max(flag: int) -> int          -> max of `flag` over ranks (identity if world == 1)
       have_update_callback                      -> must agree on all ranks (default: on_update given)
     """
     if all_reduce_max is None:
         def all_reduce_max(v):
             return v
+    if gather is None:
+        def gather(t):
+            return gather_tiles(t, world, rank)
     updates_on = (on_update is not None) if have_update_callback is None else bool(have_update_callback)
 
     def stop_agreed():
@@ -107,7 +113,7 @@ def progressive_trace(launch, tile, world, rank, iterations, samples, update_int
         else:
             launch(samples, i == 0, upd or e + 1 == iterations)
         if upd:
-            frame = gather_tiles(tile(), world, rank)
+            frame = gather(tile())
             if rank == 0 and on_update is not None:
                 on_update(frame)
         i = e + 1
@@ -115,172 +121,150 @@ def progressive_trace(launch, tile, world, rank, iterations, samples, update_int
         return False
     if iterations == 0:
         return True
-    frame = gather_tiles(tile(), world, rank)
+    frame = gather(tile())
     if rank == 0 and on_finished is not None:
         on_finished(frame)
     return True
 
 
+class NativeExchange:
+    """The product exchange of one-process-per-GPU jobs: the band tracer joins the library's group
+    (rt_tracer_join_group, RCCL); from then on every emitting TraceEnqueue/Launch carries its own gather."""
+
+    def attach(self, job):
+        uid = [None]
+        if job.rank == 0 and job.world > 1:
+            from .api import group_unique_id
+            uid[0] = group_unique_id()
+        if job.world > 1:
+            job.dist.broadcast_object_list(uid, src=0)      # 128 bytes through the launcher's rendezvous
+        job.tracer.JoinGroup(job.world, job.rank, uid[0])
+
+    def after_emit(self, job):
+        pass                                                # the library enqueued the gather behind the launch
+
+    def frame(self, job):
+        """(H, W) uint32 on rank 0 (waits for its own streams and the gather), None elsewhere."""
+        if job.rank != 0:
+            job.tracer.Sync()
+            return None
+        return job.tracer.Frame()
+
+
 class RowBandJob:
-    """One rank's share of a frame: a tracer on its band + the tile gather.
+    """One frame in row bands + the tile gather, in one of three shapes:
 
-    weak=True  : the frame is W x (H*world) and every rank owns H rows (fixed per-GPU work).
-    weak=False : the frame is W x H split into `world` bands (strong scaling)."""
+      world == 1, devices None   one tracer, the whole frame (single GPU);
+      world == 1, devices [...]  rt_tracer_create_multi: band k on devices[k], everything inside the library;
+      world  > 1                 this process is rank `rank`: a band tracer that joined the group.
 
-    def __init__(self, cfg, tris, spheres, world=1, rank=0, local_rank=0, weak=True,
-                 samples_in_flight=0, lds_chunk=0, math_mode=0):
-        import raytracertest_amd as R
+    weak=True  : the frame is W x (H*G) and every band has H rows (fixed per-GPU work), G = bands or ranks;
+    weak=False : the frame is W x H split into G bands (strong scaling).
+    exchange / tracer_factory are seams for the CPU tests (an oracle-backed tracer, a host-staged exchange)."""
+
+    def __init__(self, cfg, tris, spheres, world=1, rank=0, local_rank=0, weak=True, devices=None,
+                 samples_in_flight=0, lds_chunk=0, math_mode=0, exchange=None, tracer_factory=None):
         self.cfg, self.world, self.rank = cfg, world, rank
-        self.torch = None
-        if world > 1:
-            import torch
-            import torch.distributed as dist
-            self.torch, self.dist = torch, dist
-            # Rehearsal knobs (a 1-GPU box cannot host two RCCL ranks): RT_DIST_BACKEND=gloo stages the
-            # tiles through host memory for the collective, RT_DIST_SHARE_GPU=1 lets all ranks use
-            # the devices round-robin.  The product path is nccl (RCCL), one GPU per rank.
-            import os
-            self.backend = os.environ.get("RT_DIST_BACKEND", "nccl")
-            if os.environ.get("RT_DIST_SHARE_GPU", "") == "1":
-                local_rank = local_rank % max(torch.cuda.device_count(), 1)
-            torch.cuda.set_device(local_rank)
-            if not dist.is_initialized():
-                if self.backend == "nccl":
-                    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-                else:
-                    dist.init_process_group(backend=self.backend)
+        self.dist = None
         W, H = cfg["width"], cfg["height"]
-        if weak:
-            full_h, row0, rows = H * world, H * rank, H
-            self.all_rows = [H] * world
+        parts = world if world > 1 else (len(devices) if devices else 1)
+        self.parts = parts
+        full_h = H * parts if weak else H
+        self.full_height = full_h
+        if world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+            if not dist.is_initialized():
+                dist.init_process_group(backend="gloo")     # control plane only: id, barrier, max, stop agreement
+            row0, rows = band_rows(full_h, world, rank)
         else:
-            full_h = H
-            row0, rows = band_rows(H, world, rank)
-            self.all_rows = [band_rows(H, world, r)[1] for r in range(world)]
-        self.full_height, self.row0, self.rows = full_h, row0, rows
-        self.tracer = R.RayTracer((W, rows), (0.0, 0.0, 0.0), cfg["angles"], cfg["fov"], cfg["focal"],
-                                  cfg["aperture"], seed=cfg["seed"], device=local_rank, math_mode=math_mode,
-                                  full_height=full_h if world > 1 else 0, row_begin=row0,
-                                  samples_in_flight=samples_in_flight, lds_chunk=lds_chunk)
+            row0, rows = 0, full_h
+        self.row0, self.rows = row0, rows
+        if tracer_factory is None:
+            import raytracertest_amd as R
+
+            def tracer_factory(**kw):
+                return R.RayTracer((W, rows), (0.0, 0.0, 0.0), cfg["angles"], cfg["fov"], cfg["focal"], cfg["aperture"],
+                                   seed=cfg["seed"], math_mode=math_mode, samples_in_flight=samples_in_flight,
+                                   lds_chunk=lds_chunk, **kw)
+        if world > 1:
+            self.tracer = tracer_factory(device=local_rank, full_height=full_h, row_begin=row0)
+        elif devices:
+            self.tracer = tracer_factory(devices=list(devices))
+        else:
+            self.tracer = tracer_factory(device=local_rank)
         if tris.shape[0]:
             assert self.tracer.UploadScene(tris)
         if spheres.shape[0]:
             self.tracer.UploadSpheres(spheres)
-        self.frame = None
-        self.step_index = 0
+        self.exchange = None
         if world > 1:
-            t = self.torch
-            tallest = max(self.all_rows)
-            # two tile buffers: frame i is gathered from one while frame i+1 is copied into the other
-            self.tiles = [t.zeros((tallest, W), dtype=t.int32, device="cuda") for _ in range(2)]
-            self.recv = [[t.empty((tallest, W), dtype=t.int32, device="cuda") for _ in range(world)] for _ in range(2)] \
-                if rank == 0 else [None, None]
-            dev = t.device("cuda", local_rank)
-            # the tracer's own HIP streams: trace launches run as two half-frame kernels on two streams
-            self.trace_streams = [t.cuda.ExternalStream(self.tracer.Stream(), device=dev),
-                                  t.cuda.ExternalStream(self.tracer.StreamB(), device=dev)]
-            self.copied = [[t.cuda.Event() for _ in range(2)] for _ in range(2)]   # tile i written, one event per stream
-            self.gathered = [t.cuda.Event() for _ in range(2)]    # tile i consumed by the gather (torch's stream)
+            self.exchange = exchange if exchange is not None else NativeExchange()
+            self.exchange.attach(self)
 
     # ---- throughput path (bench.py) -------------------------------------------------------
     def step(self):
-        """One Trace pass on device-resident buffers (+ tile gather when sharded).  Nothing here
-        blocks the host: the trace kernel writes its BGRA8 tile straight into the gather's send
-        buffer, the gather is ordered behind the trace through an event, and buffer reuse behind
-        the previous gather."""
-        cfg = self.cfg
-        if self.world == 1:
-            self.tracer.TraceEnqueue(cfg["iterations"], cfg["samples"])
-            return
-        from .api import BUF_IMAGE
-        b = self.step_index & 1
-        self.step_index += 1
-        for s in self.trace_streams:
-            s.wait_event(self.gathered[b])                        # buffer b is free again (no-op the first time)
-        self.tracer.SetImageMirror(self.tiles[b].data_ptr())      # the kernel writes the send buffer itself: no copy
-        self.tracer.TraceEnqueue(cfg["iterations"], cfg["samples"])
-        cur = self.torch.cuda.current_stream()
-        for ev, s in zip(self.copied[b], self.trace_streams):     # the gather waits for both halves, neither stream waits
-            ev.record(s)
-            cur.wait_event(ev)
-        if self.backend == "nccl":
-            self.dist.gather(self.tiles[b], self.recv[b] if self.rank == 0 else None, dst=0)
-        else:                                                    # rehearsal: collective on host copies
-            host = self.tiles[b].cpu()
-            parts = [self.torch.empty_like(host) for _ in range(self.world)] if self.rank == 0 else None
-            self.dist.gather(host, parts, dst=0)
-            if self.rank == 0:
-                for dst, src in zip(self.recv[b], parts):
-                    dst.copy_(src)
-        self.gathered[b].record(cur)
-        self.last_buffer = b
+        """One Trace pass on device-resident buffers + the gather of the finished tiles when the frame is
+        sharded.  Nothing here blocks the host: the trace kernel writes its tile straight into the gather's
+        buffer, the gather runs on its own stream behind an event while the next step already traces."""
+        self.tracer.TraceEnqueue(self.cfg["iterations"], self.cfg["samples"])
+        if self.exchange is not None:
+            self.exchange.after_emit(self)
 
     def finish(self):
         self.tracer.Sync()
-        if self.world > 1:
-            self.torch.cuda.synchronize()
 
     def gathered_image(self):
-        """(full rows, W) uint32 BGRA8 on rank 0 after finish() (None elsewhere)."""
+        """(full rows, W) uint32 BGRA8 of the last step on rank 0 (None elsewhere)."""
         if self.world == 1:
             return self.tracer.Image()
-        if self.rank != 0 or self.step_index == 0:
-            return None
-        t = self.torch
-        parts = [buf[:r] for buf, r in zip(self.recv[self.last_buffer], self.all_rows)]
-        return t.cat(parts, dim=0).cpu().numpy().view(np.uint32)
+        return self.exchange.frame(self)
 
     # ---- progressive path (callbacks on rank 0) ---------------------------------------------
-    def _tile(self):
-        """Finished BGRA8 band as a torch tensor ready for the collective (host-syncs the tracer)."""
-        from .api import BUF_IMAGE
-        if self.world == 1:
-            import torch
-            return torch.from_numpy(self.tracer.Image().view(np.int32))
-        tile = self.tiles[0][:self.rows]
-        self.tracer.CopyToDevice(BUF_IMAGE, tile.data_ptr(), self.rows * self.cfg["width"] * 4)
-        return tile if self.backend == "nccl" else tile.cpu()
-
     def trace_progressive(self, iterations, samples, update_interval, on_update=None, on_finished=None,
                           stop_requested=None):
-        """Multi-GPU Trace with the reference's callback cadence; callbacks run on rank 0 with
-        the gathered (full rows, W) frame.  Whether updates happen at all is rank 0's choice
-        (it passes on_update), agreed on by all ranks."""
+        """Multi-rank Trace with the reference's callback cadence; callbacks run on rank 0 with the gathered
+        (full rows, W) uint32 frame.  Whether updates happen at all is rank 0's choice, agreed on by all ranks.
+        (A single-process job calls tracer.Trace() instead: the library runs this loop itself.)"""
         updates_on = bool(self._all_reduce_max(1 if (self.rank == 0 and on_update is not None) else 0))
-
         fuse = self.tracer.FusedIterations(samples)            # same on every rank (same build, same options)
 
         def launch(spp, clear_first, emit, n=1):
             self.tracer.Launch(spp, clear_first, emit, iterations=n)
+            if emit and self.exchange is not None:
+                self.exchange.after_emit(self)
 
-        ok = progressive_trace(launch, self._tile, self.world, self.rank, iterations, samples, update_interval,
+        ok = progressive_trace(launch, lambda: None, self.world, self.rank, iterations, samples, update_interval,
                                on_update=on_update if self.rank == 0 else None, on_finished=on_finished,
                                stop_requested=stop_requested, all_reduce_max=self._all_reduce_max,
-                               have_update_callback=updates_on, fuse=fuse)
+                               have_update_callback=updates_on, fuse=fuse, gather=lambda _t: self.gathered_image())
         self.tracer.Sync()
         return ok
 
     def _all_reduce_max(self, v):
         if self.world == 1:
             return v
-        t = self.torch.tensor([int(v)], dtype=self.torch.int32, device="cuda" if self.backend == "nccl" else "cpu")
+        import torch
+        t = torch.tensor([int(v)], dtype=torch.int32)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return int(t.item())
 
     # ---- bench plumbing ----------------------------------------------------------------------
     def barrier(self):
+        """All ranks have drained their device work and reached this point."""
+        self.tracer.Sync()
         if self.world > 1:
             self.dist.barrier()
-            self.torch.cuda.synchronize()
 
     def max_over_ranks(self, seconds):
         if self.world == 1:
             return seconds
-        t = self.torch.tensor([seconds], dtype=self.torch.float64, device="cuda" if self.backend == "nccl" else "cpu")
+        import torch
+        t = torch.tensor([seconds], dtype=torch.float64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
-    def close(self):
+    def close(self, destroy_group=True):
         self.tracer.close()
-        if self.world > 1 and self.dist.is_initialized():
+        if destroy_group and self.world > 1 and self.dist.is_initialized():
             self.dist.destroy_process_group()

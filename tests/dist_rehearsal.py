@@ -1,26 +1,28 @@
 #!/usr/bin/env python3
-"""Rehearsal of the N > 1 bench/driver path on a box with ONE GPU: two ranks share device 0 and
-the collective runs over gloo (RCCL refuses two ranks on one device).  Launched by
-tests/test_gpu_parity.py through torch.distributed.run.  Checks on rank 0 that the frame
-gathered by RowBandJob.step() equals a single tracer on the whole frame, and that the
-progressive driver fires the reference's callback cadence."""
+"""Rehearsal of the one-process-per-GPU job on a box with ONE GPU: two ranks (torch.distributed.run) share
+device 0.  RCCL refuses two ranks on one device, so the tiles travel through the test's HostStagedExchange
+(tests/dist_helpers.py) instead of the library's group; everything else is the product path of
+raytracertest_amd.dist.RowBandJob -- band geometry, gloo control plane, band tracers with global-row RNG keys,
+progressive driver.  Checks on rank 0 that the gathered frame equals a single tracer on the whole frame and that
+the progressive driver fires the reference's callback cadence.  Launched by tests/test_gpu_parity.py."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 
-os.environ.setdefault("RT_DIST_BACKEND", "gloo")
-os.environ.setdefault("RT_DIST_SHARE_GPU", "1")
 import raytracertest_amd as R
 from raytracertest_amd import scenes
 from raytracertest_amd.dist import RowBandJob
+from dist_helpers import HostStagedExchange
 
-world, rank, local = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"])
+world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
 cfg = dict(width=64, height=24, iterations=2, samples=3, angles=(0.0, 0.0), fov=70.0, focal=3.0, aperture=0.05, seed=9)
 tris = scenes.cornell32()
 for weak in (True, False):
-    job = RowBandJob(cfg, tris, np.zeros((0, 4), np.float32), world=world, rank=rank, local_rank=local, weak=weak)
-    for _ in range(3):                     # three steps: exercises both tile buffers and their reuse
+    job = RowBandJob(cfg, tris, np.zeros((0, 4), np.float32), world=world, rank=rank, local_rank=0, weak=weak,
+                     exchange=HostStagedExchange())
+    for _ in range(3):
         job.step()
     job.finish()
     frame = job.gathered_image()
@@ -40,12 +42,12 @@ for weak in (True, False):
         assert frame is None
     updates, finished = [], []
     ok = job.trace_progressive(5, 1, 2, on_update=(lambda f: updates.append(1)) if rank == 0 else None,
-                               on_finished=lambda f: finished.append(f.numpy().view(np.uint32).copy()))
+                               on_finished=lambda f: finished.append(np.array(f, copy=True)))
     assert ok
     if rank == 0:
         assert len(updates) == 2 and len(finished) == 1 and finished[0].shape[1] == cfg["width"]
     job.barrier()
-    job.tracer.close()
+    job.close(destroy_group=False)
 import torch.distributed as dist
 dist.destroy_process_group()
 if rank == 0:

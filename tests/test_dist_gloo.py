@@ -155,3 +155,61 @@ def test_progressive_stop_is_agreed_by_all_ranks(tmp_path):
     assert not bool(r["ok"]) and int(r["n_updates"]) == 1 and int(r["n_finished"]) == 0   # stopped after the first update
     c0, c1 = np.load(os.path.join(str(tmp_path), "counts0.npy")), np.load(os.path.join(str(tmp_path), "counts1.npy"))
     assert (c0 == 8).all() and (c1 == 8).all()      # both ranks ran exactly launches 0..3, then left together
+
+
+# ---------------------------------------------------------------- RowBandJob's own host logic, one process per rank
+def _job_worker(rank, world, port, outdir, weak):
+    import sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from dist_helpers import HostStagedExchange, OracleBackedTracer
+    from raytracertest_amd import scenes
+    from raytracertest_amd.dist import RowBandJob
+    cfg = dict(width=37, height=11, iterations=2, samples=2, angles=(0.0, 0.0), fov=70.0, focal=3.0, aperture=0.05, seed=4)
+    made = {}
+
+    def factory(device=0, full_height=0, row_begin=0, **kw):
+        rows = (full_height * (rank + 1)) // world - (full_height * rank) // world
+        made["t"] = OracleBackedTracer(cfg["width"], full_height, row_begin, rows, cfg)
+        return made["t"]
+
+    job = RowBandJob(cfg, scenes.cornell32(), np.zeros((0, 4), np.float32), world=world, rank=rank, local_rank=rank, weak=weak,
+                     exchange=HostStagedExchange(), tracer_factory=factory)
+    assert (job.row0, job.rows) == ((job.full_height * rank) // world, made["t"].o.rows)
+    for _ in range(2):
+        job.step()
+    job.finish()
+    frame = job.gathered_image()
+    job.barrier()
+    assert abs(job.max_over_ranks(1.0 + rank) - world) < 1e-9
+    updates, finished = [], []
+    ok = job.trace_progressive(5, 1, 2, on_update=(lambda f: updates.append(f.copy())) if rank == 0 else None,
+                               on_finished=lambda f: finished.append(f.copy()))
+    if rank == 0:
+        np.savez(os.path.join(outdir, "job.npz"), frame=frame, ok=ok, n_updates=len(updates), final=finished[0],
+                 full_height=job.full_height, launches=np.array(made["t"].launch_log))
+    else:
+        assert frame is None and ok
+    job.close()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("weak", [True, False])
+def test_row_band_job_over_two_ranks_with_an_oracle_backed_tracer(tmp_path, orc, weak):
+    """dist.RowBandJob as bench.py and the progressive driver use it, two gloo ranks on CPU: band geometry (weak: the
+    frame grows, strong: it is split), step/finish/gathered_image, barrier and max over ranks, the progressive loop
+    with launch fusion -- the frames equal the oracle's whole frame."""
+    import torch.multiprocessing as mp
+    from raytracertest_amd import scenes
+    world = 2
+    mp.spawn(_job_worker, args=(world, _free_port(), str(tmp_path), weak), nprocs=world, join=True)
+    r = np.load(os.path.join(str(tmp_path), "job.npz"))
+    H = 22 if weak else 11
+    assert int(r["full_height"]) == H and bool(r["ok"]) and int(r["n_updates"]) == 2
+    whole = orc.OracleTracer(37, H, (0.0, 0.0), 70.0, 3.0, 0.05, seed=4, nthreads=4)
+    whole.upload_scene(scenes.cornell32())
+    whole.trace(2, 2); whole.trace(2, 2)
+    assert np.array_equal(r["frame"], whole.image)
+    whole.trace(5, 1)
+    assert np.array_equal(r["final"], whole.image)
+    assert r["launches"].tolist() == [3, 2]        # fuse = 4: iterations 0..2 (update at 2), 3..4 (update at 4 = the end)

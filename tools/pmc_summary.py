@@ -14,6 +14,10 @@ shutil.copy(stats[0], os.path.join(dst, "%s_c3_kernel_stats.csv" % tag))
 stats4 = sorted(glob.glob(os.path.join(src, "stats_c4", "*", "*kernel_stats.csv")), key=os.path.getmtime, reverse=True)
 if stats4:
     shutil.copy(stats4[0], os.path.join(dst, "%s_c4_kernel_stats.csv" % tag))
+# the kernel build the profiled runs used (rt_version() carries a hash of the kernel sources + flags); bench.py
+# prints the PMC-derived figures only when the library it loaded has the same hash
+lib = json.loads(open(os.path.join(src, "bench_c3.json")).read().strip().splitlines()[-1])["config"].get("library", "")
+khash = lib.split("kernels=")[-1].rstrip(")") if "kernels=" in lib else None
 rows = []
 means = {}
 for p in ("pmc_fetch", "pmc_write", "pmc_sq"):
@@ -36,6 +40,7 @@ npix = 1920 * 1080
 alg = npix * (2 * 24 + 32) + 48 * 32
 traffic = int(round((fetch_kb * 2.0 + write_kb) * 1024))
 json.dump({
+    "kernel_source_hash": khash,
     "_method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a separate pass, --pmc WRITE_SIZE around `python3 bench.py --steps 5 --warmup 1 "
                "--cpu-rows 0 --no-valu` (%s, tools/profile_round.sh). Counter unit KB; FETCH_SIZE x2 on gfx950 as MI355X_MICROARCH.md prescribes "
                "(factor calibrated in round 1 on convert_kernel, profiles/r01_pmc_c3_fetch.csv). Per-kernel means: profiles/%s_c3_pmc_summary.csv." % (tag, tag),
@@ -62,6 +67,7 @@ if f4:
                  "waves": int(m4[(t4, "SQ_WAVES")]), "valu_per_wave": round(m4[(t4, "SQ_INSTS_VALU")] / m4[(t4, "SQ_WAVES")], 1),
                  "lane_instructions_per_ray": round(v4 * 64 / (3840 * 2160 * 64), 1)}}
 json.dump({
+    "kernel_source_hash": khash,
     "_method": "rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE "
                "(%s, own pass). Per-launch means for the C3 trace kernel; wave-level instruction counts (one count per wave64 instruction)." % tag,
     "C3": {"kernels_per_launch": kpl, "valu_wave_instructions_per_launch": int(valu), "salu": int(means[(tk, "SQ_INSTS_SALU")]), "lds": int(means[(tk, "SQ_INSTS_LDS")]),
@@ -69,3 +75,8 @@ json.dump({
            "lane_instructions_per_ray": round(valu * 64 / (npix * 16), 1)}, **c4},
     open(os.path.join(dst, "valu_issue.json"), "w"), indent=1)
 print("traffic %d B/launch (algorithmic %d), VALU wave-instructions/launch %d (%.0f per wave)" % (traffic, alg, valu, valu / means[(tk, "SQ_WAVES")]))
+
+# overlap of the two half-frame kernels of a launch, from the kernel trace of the --stats pass
+import subprocess
+subprocess.run([sys.executable, os.path.join(root, "tools", "overlap.py"), os.path.join(src, "stats"),
+                os.path.join(dst, "%s_c3_overlap.csv" % tag)], check=False)
