@@ -60,8 +60,9 @@ constexpr uint32_t TRACE_LISTS_LOAD = 16u;
 // large-scene kernels: per-sample conservative forms per candidate (9 more floats per LDS record)
 constexpr uint32_t TRACE_PRETEST = 32u;
 
+// jump: J^(2^k), k < 32, 160 columns x 8 words; win: the 4-bit window tables of J^(2^m), m < 6 (rt_rng_host.hpp)
 hipError_t launch_rng_init(uint32_t* rng, uint32_t npix, uint32_t p0, const uint32_t seeded[6],
-                           const uint32_t* jump, hipStream_t st);
+                           const uint32_t* jump, const uint32_t* win, hipStream_t st);
 hipError_t launch_prep_triangles(bool fma, bool edges, const float4* verts, uint32_t n, float4* tri_a, float* tri_b,
                                  float4* color, float4* normals, hipStream_t st);
 uint32_t trace_lds_bytes(const TraceParams& p, bool bin);

@@ -55,6 +55,27 @@ inline std::vector<uint32_t> build_jump_table() {
   return table;
 }
 
+// 4-bit window tables of the six lowest jump powers J^(2^m), m = 0..5 (what distinguishes the 64 pixels of a
+// wave): entry [m][g][n] = XOR of the columns g*4 + j of J^(2^m) over the set bits j of the nibble n, so that a
+// matrix-vector product is 40 table look-ups instead of 160 masked column XORs (rng_init_kernel keeps the
+// tables in LDS).  Device layout: 6*40*16 entries of words 0..3 (16 bytes each), then the same entries' word 4.
+constexpr uint32_t kWindowMatrices = 6, kWindowGroups = 40, kWindowEntries = kWindowMatrices * kWindowGroups * 16u;
+inline std::vector<uint32_t> build_window_tables(const std::vector<uint32_t>& jump) {
+  std::vector<uint32_t> t(static_cast<size_t>(kWindowEntries) * 5u, 0u);
+  for (uint32_t m = 0; m < kWindowMatrices; ++m)
+    for (uint32_t g = 0; g < kWindowGroups; ++g)
+      for (uint32_t n = 0; n < 16u; ++n) {
+        uint32_t r[5] = {0, 0, 0, 0, 0};
+        for (uint32_t j = 0; j < 4u; ++j)
+          if ((n >> j) & 1u)
+            for (int w = 0; w < 5; ++w) r[w] ^= jump[(static_cast<size_t>(m) * 160u + g * 4u + j) * 8u + w];
+        const size_t e = (static_cast<size_t>(m) * kWindowGroups + g) * 16u + n;
+        memcpy(&t[e * 4u], r, 4 * sizeof(uint32_t));
+        t[static_cast<size_t>(kWindowEntries) * 4u + e] = r[4];
+      }
+  return t;
+}
+
 // seed scramble of curand_init: state = {d, v0..v4}
 inline void seed_state(uint64_t seed, uint32_t s[6]) {
   const uint32_t lo = static_cast<uint32_t>(seed) ^ 0xaad26b49u;

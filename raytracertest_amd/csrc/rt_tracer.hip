@@ -54,7 +54,7 @@ struct HipFail { std::string what; };
 // jump table: built once per process, uploaded once per device
 std::mutex g_jump_mu;
 std::vector<uint32_t> g_jump_host;
-std::map<int, uint32_t*> g_jump_dev;
+std::map<int, uint32_t*> g_jump_dev;    // per device: the jump table followed by the window tables
 
 const std::vector<uint32_t>& jump_host() {
   std::lock_guard<std::mutex> lk(g_jump_mu);
@@ -62,14 +62,18 @@ const std::vector<uint32_t>& jump_host() {
   return g_jump_host;
 }
 
+constexpr size_t kJumpWords = 32u * 160u * 8u;
+
 uint32_t* jump_device(int device) {
   const std::vector<uint32_t>& h = jump_host();
   std::lock_guard<std::mutex> lk(g_jump_mu);
   auto it = g_jump_dev.find(device);
   if (it != g_jump_dev.end()) return it->second;
+  static const std::vector<uint32_t> win = rth::build_window_tables(h);
   uint32_t* d = nullptr;
-  HIP_CHECK(hipMalloc(&d, h.size() * sizeof(uint32_t)));
+  HIP_CHECK(hipMalloc(&d, (h.size() + win.size()) * sizeof(uint32_t)));
   HIP_CHECK(hipMemcpy(d, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  HIP_CHECK(hipMemcpy(d + h.size(), win.data(), win.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   g_jump_dev[device] = d;
   return d;
 }
@@ -238,7 +242,9 @@ struct rt_tracer {
     uint32_t seeded[6];
     rth::seed_state(seed, seeded);
     const uint32_t p0 = row0 * W;                                        // subsequence of the band's first pixel
-    HIP_CHECK(rtk::launch_rng_init(d_rng, npix(), p0, seeded, jump_device(device), main_stream()));
+    if (static_cast<uint64_t>(W) * H > 0xFFFFFFFFull) throw HipFail{"frames above 2^32 pixels are not supported (32-bit pixel index, Kernels.cuh:128)"};
+    uint32_t* const tables = jump_device(device);
+    HIP_CHECK(rtk::launch_rng_init(d_rng, npix(), p0, seeded, tables, tables + kJumpWords, main_stream()));
   }
 
   void create_buffers() {                                                // ctor :33-40, Resize :96-102

@@ -57,7 +57,7 @@ def test_cpp_cli_builds_and_fails_loudly_without_gpu(tmp_path):
 
 
 @pytest.mark.gpu
-def test_cli_cpp_and_python_write_the_same_bmp_as_the_api(tmp_path):
+def test_cli_cpp_and_python_write_the_same_bmp_as_the_api(tmp_path, orc):
     import raytracertest_amd as R
     from raytracertest_amd import scenes
     from raytracertest_amd.bitmap import read_bmp
@@ -75,10 +75,33 @@ def test_cli_cpp_and_python_write_the_same_bmp_as_the_api(tmp_path):
     assert g.Wait()
     assert open(str(tmp_path / "c.bmp"), "rb").read() == open(str(tmp_path / "p.bmp"), "rb").read()
     assert np.array_equal(read_bmp(str(tmp_path / "c.bmp")), g.Image())
+    o = orc.OracleTracer(96, 54, (0.0, 0.0), 70.0, 3.0, 0.05, seed=7, nthreads=4)      # ... and as the oracle's image
+    o.upload_scene(scenes.cornell32())
+    o.trace(3, 4)
+    assert np.array_equal(read_bmp(str(tmp_path / "c.bmp")), o.image)
     # the reference's integer angle flag: -cya 180 looks at the demo triangles behind the camera
     subprocess.run([exe, "-w", "38", "-h", "21", "-s", "1", "-i", "4", "-u", "0", "-cya", "172", "--aperture", "0.5",
                     "--seed", "3", "-o", str(tmp_path / "d.bmp"), "-q"], check=True, timeout=120)
     assert len(np.unique(read_bmp(str(tmp_path / "d.bmp")))) > 3
+
+
+@pytest.mark.gpu
+def test_cli_reference_default_invocation_equals_the_oracle(tmp_path, orc):
+    """The reference app started with no flags (OpenGLView/App.cpp:11-23: 38x21, 100 iterations x 1 sample, update every
+    10, fov 70, focal 10, aperture 4; demo scene MainFrame.cpp:230-232) -- only --seed added, the reference seeds from
+    the clock (Random.cu:45): the BMP both CLIs write is the oracle's image, and so is every BGRA8 update on the way."""
+    from raytracertest_amd import scenes
+    from raytracertest_amd.bitmap import read_bmp
+    exe = gpp(os.path.join(ROOT, "tools", "rt_cli.cpp"), str(tmp_path / "rt_cli"))
+    subprocess.run([exe, "--seed", "11", "-o", str(tmp_path / "c.bmp"), "-q"], check=True, timeout=120)
+    subprocess.run([sys.executable, "-m", "raytracertest_amd.cli", "--seed", "11", "-o", str(tmp_path / "p.bmp"), "-q"],
+                   check=True, timeout=300, cwd=ROOT)
+    o = orc.OracleTracer(38, 21, (0.0, 0.0), 70.0, 10.0, 4.0, seed=11, nthreads=2)
+    o.upload_scene(scenes.demo3())
+    o.trace(100, 1)
+    assert np.array_equal(read_bmp(str(tmp_path / "c.bmp")), o.image)
+    assert np.array_equal(read_bmp(str(tmp_path / "p.bmp")), o.image)
+    assert len(np.unique(o.image)) > 3          # (farthest hit with negative t accepted: the triangles behind the camera show)
 
 
 @pytest.mark.gpu
