@@ -160,7 +160,7 @@ class RowBandJob:
 
     weak=True  : the frame is W x (H*G) and every band has H rows (fixed per-GPU work), G = bands or ranks;
     weak=False : the frame is W x H split into G bands (strong scaling).
-    exchange / tracer_factory are seams for the CPU tests (an oracle-backed tracer, a host-staged exchange)."""
+    exchange / tracer_factory are seams for the tests (a CPU stand-in for the tracer, a host-staged exchange)."""
 
     def __init__(self, cfg, tris, spheres, world=1, rank=0, local_rank=0, weak=True, devices=None,
                  samples_in_flight=0, lds_chunk=0, math_mode=0, exchange=None, tracer_factory=None):

@@ -581,8 +581,8 @@ def test_launch_building_block_and_progressive_driver(rt, orc):
     cfg = dict(width=48, height=28, iterations=1, samples=2, angles=(0.0, 0.0), fov=70.0, focal=3.0, aperture=0.05, seed=1)
     job = RowBandJob(cfg, scenes.cornell32(), np.zeros((0, 4), np.float32))
     updates, finished = [], []
-    ok = job.trace_progressive(7, 2, 3, on_update=lambda f: updates.append(f.numpy().view(np.uint32).copy()),
-                               on_finished=lambda f: finished.append(f.numpy().view(np.uint32).copy()))
+    ok = job.trace_progressive(7, 2, 3, on_update=lambda f: updates.append(f.copy()),
+                               on_finished=lambda f: finished.append(f.copy()))
     assert ok and len(updates) == 2 and len(finished) == 1
     o = orc.OracleTracer(48, 28, (0.0, 0.0), 70.0, 3.0, 0.05, seed=1, nthreads=4)
     o.upload_scene(scenes.cornell32())
@@ -596,9 +596,9 @@ def test_launch_building_block_and_progressive_driver(rt, orc):
 
 
 def test_stream_interop_for_the_overlapped_gather(rt):
-    """The pieces dist.RowBandJob.step() relies on for N > 1, exercised on one GPU: the tracer's
-    HIP stream wrapped as a torch ExternalStream, an async copy ordered behind the trace, an
-    event making torch's stream wait for it."""
+    """Stream interop for an external driver that orders its OWN device work behind the tracer (rt_tracer_stream):
+    the tracer's HIP stream wrapped as a torch ExternalStream, an async copy ordered behind the trace, an
+    event making torch's stream wait for it.  (The library's own tile gather does the same with its gather streams.)"""
     import torch
     import raytracertest_amd as R
     from raytracertest_amd import scenes
