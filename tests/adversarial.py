@@ -7,12 +7,16 @@ decision boundary, so this generator aims at them.  For a camera and a frame it 
 tile-corner pixels, lens samples on the rim of the aperture or at its centre -- and builds triangles
 
   edge      a point of the ray lies exactly on an edge or a vertex (u = 0, v = 0, u + v = 1), then every
-            coordinate is moved by up to +-64 ulp: hit/miss of that ray flips inside the family;
+            coordinate is moved by 0, 1, 2, 4, 16 or 64 ulp at most: hit/miss of that ray flips inside the family;
   plane     the triangle's plane contains the ray (det = 0) up to a tilt of 0, 1e-7 ... 1e-3 rad, both windings:
             the culling bound det_hi < eps * |w| decides;
   epsdet    facing the ray, sized so that det lands within a factor of 30 of the culling epsilon 1e-10;
   focal     a vertex at the focal point of a tile-corner pixel (+- ulps): in-focus geometry, where the
             family's bounds are tightest, grazing the corner of the tile's focal box;
+  graze     touches the family from OUTSIDE: one vertex on the ray of a tile-corner pixel, the rest of the
+            triangle pointing away from the tile -- every other ray of the tile misses, the corner ray sits on
+            u = v = 0; small and far (|e| down to 1e-5 of the distance), where the reference's own evaluation
+            of u, v is dominated by rounding (error ~ 10 ulp * distance / size);
   filler    plain random triangles around all of that (candidate lists of realistic length),
 
 at coordinate scales 1e-3 ... 1e4 and apertures from 0 to many times the scene.  The camera math below is a
@@ -75,20 +79,23 @@ def _pick_ray(rng, cam, W, H):
         th = rng.uniform(0, 2 * np.pi)
         r = rng.choice([1.0, 1.0, 0.999999, 0.5])
         lens = (r * np.cos(th), r * np.sin(th))
-    return family_ray(cam, W, H, px, py, lens)
+    o, d, focal = family_ray(cam, W, H, px, py, lens)
+    _, dc, _ = family_ray(cam, W, H, tx * 8 + 3.5, ty * 8 + 3.5, lens)      # the tile's central ray: "away from the tile"
+    return o, d, focal, dc
 
 
 def adversarial_triangles(rng, cam, W, H, n, scale):
     """(n, 3, 3) float32 triangles around the rays of the camera's tile families (see the module docstring)."""
     tris = np.zeros((n, 3, 3), np.float64)
-    kinds = rng.choice(5, n, p=[0.3, 0.25, 0.1, 0.15, 0.2])
+    kinds = rng.choice(6, n, p=[0.2, 0.2, 0.1, 0.1, 0.15, 0.25])
+    jitter = rng.choice([0, 1, 2, 4, 16, 64], n, p=[0.15, 0.2, 0.2, 0.2, 0.15, 0.1])
     for i in range(n):
-        o, d, focal = _pick_ray(rng, cam, W, H)
+        o, d, focal, dc = _pick_ray(rng, cam, W, H)
         t = float(rng.choice([-1.0, 1.0, 1.0, 1.0]) * scale * 10.0 ** rng.uniform(-1.0, 1.0))
         if rng.integers(0, 3) == 0:
             t = float(np.linalg.norm(focal - o))                      # in focus
         P = o + t * d
-        size = abs(t) * 10.0 ** rng.uniform(-3.0, 0.3) + 1e-30
+        size = abs(t) * 10.0 ** rng.uniform(-5.0, 0.3) + 1e-30
         k = kinds[i]
         if k == 0:                                                    # edge / vertex through the ray
             a, b = _perp(rng, d), _perp(rng, d)
@@ -117,13 +124,26 @@ def adversarial_triangles(rng, cam, W, H, n, scale):
         elif k == 3:                                                  # a vertex at the focal point of a tile-corner pixel
             a, b = _perp(rng, d), _perp(rng, d)
             tris[i] = (focal, focal + a * size, focal + b * size + d * size * rng.uniform(-1, 1))
+        elif k == 5:                                                  # touches the tile's family from outside at a corner ray
+            out = d - dc
+            out -= d * (out @ d)
+            nn = np.linalg.norm(out)
+            out = out / nn if nn > 1e-14 else _perp(rng, d)
+            side = np.cross(d, out)
+            v1 = P + (out + side * rng.uniform(0.0, 1.5)) * size + d * size * rng.uniform(-1, 1)
+            v2 = P + (out - side * rng.uniform(0.0, 1.5)) * size + d * size * rng.uniform(-1, 1)
+            tris[i] = (P, v1, v2) if rng.integers(0, 2) else (v1, v2, P)
         else:                                                         # filler
             c = P + rng.normal(size=3) * size
             tris[i] = c + rng.uniform(-1, 1, (3, 3)) * size
         if rng.integers(0, 2):
             tris[i] = tris[i][[0, 2, 1]]                              # both windings
     out = np.nan_to_num(tris, nan=0.0, posinf=3e38, neginf=-3e38).astype(np.float32)
-    return ulp_jitter(rng, out, 64)
+    for k in (1, 2, 4, 16, 64):
+        sel = jitter == k
+        if sel.any():
+            out[sel] = ulp_jitter(rng, out[sel], k)
+    return out
 
 
 def adversarial_config(rng, large=False):
