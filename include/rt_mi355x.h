@@ -235,6 +235,23 @@ int  rt_tracer_create_multi(const uint32_t imageSize[2], const float cameraPosit
 int  rt_group_unique_id(uint8_t id[RT_GROUP_ID_BYTES]);
 int  rt_tracer_join_group(rt_tracer* t, uint32_t n_ranks, uint32_t rank, const uint8_t id[RT_GROUP_ID_BYTES]);
 int  rt_tracer_leave_group(rt_tracer* t);
+/* The same with an explicit partition: row_begin[0..n_ranks] ascending, row_begin[0] = 0, row_begin[n_ranks] =
+ * full_height; rank r owns the rows [row_begin[r], row_begin[r+1]) (its tracer must have been created on, or
+ * moved to -- rt_tracer_set_band -- exactly those rows). */
+int  rt_tracer_join_group_bands(rt_tracer* t, uint32_t n_ranks, uint32_t rank, const uint8_t id[RT_GROUP_ID_BYTES],
+                                const uint32_t* row_begin);
+/* Load balance.  The reference scans every triangle for every ray, so equal rows are equal work there; with the
+ * per-tile classification a band costs what its tiles' candidate lists cost, and equal rows leave the bands of a dense
+ * scene uneven (C5 in 8 bands: mean/max = 0.83).  rt_balance_rows: from each band's measured cost, boundaries (multiples
+ * of `granule` rows; the kernel's tiles are 8 rows high) that equalise it, assuming the cost is spread evenly inside a
+ * band.  rt_tracer_rebalance applies it to a multi-device tracer from its bands' own kernel times since the last
+ * rt_tracer_kernel_time reset; rt_tracer_set_band moves a band tracer of a multi-process job.  Like Resize, both
+ * re-create the buffers and the RNG states of the bands (RayTracerImpl.cu:94-103); the image a Trace produces does not
+ * depend on the partition. */
+int  rt_balance_rows(uint32_t n_bands, const uint32_t* row_begin, const double* cost, uint32_t granule,
+                     uint32_t* new_row_begin);
+int  rt_tracer_rebalance(rt_tracer* t);
+int  rt_tracer_set_band(rt_tracer* t, uint32_t row_begin, uint32_t rows);
 /* Device time of the gathers since the last reset (root only; HIP events on the root's gather stream around
  * the exchange) and their number.  Zero for a frame whose bands all live on the root device. */
 int  rt_tracer_gather_time(rt_tracer* t, double* total_ms, uint64_t* gathers, int reset_after);

@@ -41,6 +41,7 @@ ABI_SYMBOLS = [
     "rt_dbg_rng_init_host",
     "rt_tracer_create_multi", "rt_group_unique_id", "rt_tracer_join_group", "rt_tracer_leave_group",
     "rt_tracer_gather_time", "rt_tracer_band_count", "rt_tracer_band_info",
+    "rt_tracer_join_group_bands", "rt_balance_rows", "rt_tracer_rebalance", "rt_tracer_set_band",
 ]
 
 
@@ -173,12 +174,27 @@ def load_library():
         L.rt_tracer_gather_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
         L.rt_tracer_band_count.argtypes = [vp]
         L.rt_tracer_band_info.argtypes = [vp, C.c_uint32, u32p]
+        L.rt_tracer_join_group_bands.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_char_p, u32p]
+        L.rt_balance_rows.argtypes = [C.c_uint32, u32p, C.POINTER(C.c_double), C.c_uint32, u32p]
+        L.rt_tracer_rebalance.argtypes = [vp]
+        L.rt_tracer_set_band.argtypes = [vp, C.c_uint32, C.c_uint32]
         _lib = L
         return _lib
 
 
 def device_count():
     return int(load_library().rt_device_count())
+
+
+def balance_rows(row_begin, cost, granule=8):
+    """Boundaries (len(cost) + 1 row indices) that equalise the bands' cost (rt_balance_rows)."""
+    b = np.ascontiguousarray(row_begin, np.uint32)
+    c = np.ascontiguousarray(cost, np.float64)
+    out = np.zeros_like(b)
+    rc = load_library().rt_balance_rows(c.size, _u32p(b), c.ctypes.data_as(C.POINTER(C.c_double)), granule, _u32p(out))
+    if rc != 0:
+        raise RtError("rt_balance_rows: invalid partition")
+    return [int(x) for x in out]
 
 
 def group_unique_id():
@@ -359,9 +375,23 @@ class RayTracer:
         return np.ascontiguousarray(np.moveaxis(planes, 0, -1))
 
     # ---- a frame sharded over several GPUs ------------------------------------------------------
-    def JoinGroup(self, n_ranks, rank, unique_id=None):
-        """This band tracer becomes rank `rank` of `n_ranks` processes that share one frame (collective call)."""
-        self._check(self._lib.rt_tracer_join_group(self._h, n_ranks, rank, unique_id))
+    def JoinGroup(self, n_ranks, rank, unique_id=None, row_begin=None):
+        """This band tracer becomes rank `rank` of `n_ranks` processes that share one frame (collective call).
+        row_begin: n_ranks + 1 boundaries of an explicit partition (default: equal bands)."""
+        if row_begin is None:
+            self._check(self._lib.rt_tracer_join_group(self._h, n_ranks, rank, unique_id))
+        else:
+            b = np.ascontiguousarray(row_begin, np.uint32)
+            self._check(self._lib.rt_tracer_join_group_bands(self._h, n_ranks, rank, unique_id, _u32p(b)))
+
+    def SetBand(self, row_begin, rows):
+        """Move a band tracer to other rows of its frame (buffers and RNG states re-created, like Resize)."""
+        self._check(self._lib.rt_tracer_set_band(self._h, row_begin, rows))
+        self.rows = int(rows)
+
+    def Rebalance(self):
+        """Multi-device tracer: re-partition the rows so that every band costs the same, from the bands' kernel times."""
+        self._check(self._lib.rt_tracer_rebalance(self._h))
 
     def LeaveGroup(self):
         self._check(self._lib.rt_tracer_leave_group(self._h))

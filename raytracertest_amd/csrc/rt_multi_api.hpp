@@ -276,7 +276,9 @@ int multi_create(const uint32_t imageSize[2], const float cameraPosition[3], con
 }
 
 // Resize of the whole frame: every band gets its new rows of the new frame; scenes, camera, options stay.
-void multi_resize(rt_tracer* t, uint32_t w, uint32_t h) {
+// begins (n + 1 ascending row indices, begins[0] = 0, begins[n] = h) gives an explicit partition
+// (rt_tracer_rebalance); null = equal bands.
+void multi_resize(rt_tracer* t, uint32_t w, uint32_t h, const uint32_t* begins = nullptr) {
   MultiState& m = *t->mg;
   Group& g = m.group;
   const uint32_t n = static_cast<uint32_t>(m.bands.size());
@@ -286,13 +288,41 @@ void multi_resize(rt_tracer* t, uint32_t w, uint32_t h) {
   multi_free_host_images(m);
   t->W = w; t->H = h; t->rows = h;
   g.W = w; g.H = h;
-  for (uint32_t k = 0; k < n; ++k) band_rows(h, n, k, g.bands[k].row0, g.bands[k].rows);
+  for (uint32_t k = 0; k < n; ++k) {
+    if (begins) { g.bands[k].row0 = begins[k]; g.bands[k].rows = begins[k + 1] - begins[k]; }
+    else band_rows(h, n, k, g.bands[k].row0, g.bands[k].rows);
+  }
   m.for_bands([&](size_t k) {
     m.bands[k]->use_device();
     m.bands[k]->reshape(w, h, g.bands[k].row0, g.bands[k].rows);
   });
   g.allocate();
   multi_alloc_host_images(t);
+}
+
+// Rows per band such that every band costs the same, from what each band cost so far (piecewise-constant cost
+// per row inside a band).  Boundaries are multiples of `granule` rows (the trace kernel's tiles are 8 rows high),
+// every band keeps at least one granule.  begins / out: n + 1 ascending row indices.
+void balance_rows(uint32_t n, const uint32_t* begins, const double* cost, uint32_t granule, uint32_t* out) {
+  const uint32_t H = begins[n];
+  if (granule == 0u) granule = 1u;
+  double total = 0.0;
+  for (uint32_t k = 0; k < n; ++k) total += cost[k] > 0.0 ? cost[k] : 0.0;
+  out[0] = 0u; out[n] = H;
+  if (!(total > 0.0) || static_cast<uint64_t>(n) * granule > H) { for (uint32_t k = 1; k < n; ++k) out[k] = begins[k]; return; }
+  uint32_t src = 0;                        // band of the old partition the sweep is in
+  double before = 0.0;                     // cost of the old bands in front of src
+  for (uint32_t k = 1; k < n; ++k) {
+    const double want = total * k / n;
+    while (src + 1u < n && before + (cost[src] > 0.0 ? cost[src] : 0.0) < want) { before += cost[src] > 0.0 ? cost[src] : 0.0; ++src; }
+    const double c = cost[src] > 0.0 ? cost[src] : 0.0;
+    const double rows_src = static_cast<double>(begins[src + 1] - begins[src]);
+    double row = begins[src] + (c > 0.0 ? (want - before) / c * rows_src : 0.0);
+    uint32_t r = static_cast<uint32_t>(row / granule + 0.5) * granule;
+    const uint32_t lo = out[k - 1] + granule;                          // at least one granule per band ...
+    const uint32_t hi = H - (n - k) * granule;                         // ... also for the bands behind
+    out[k] = r < lo ? lo : r > hi ? hi : r;
+  }
 }
 
 // whole-frame view of the per-band buffers (parity tests, host read-back)
@@ -321,10 +351,16 @@ void multi_read_buffer(rt_tracer* t, int which, void* dst, size_t bytes) {
 }
 
 // ---- a band tracer as a member of a multi-process group ----------------------------------------------
-void member_join(rt_tracer* t, uint32_t n_ranks, uint32_t rank, const uint8_t id[RT_GROUP_ID_BYTES]) {
+void member_join(rt_tracer* t, uint32_t n_ranks, uint32_t rank, const uint8_t id[RT_GROUP_ID_BYTES], const uint32_t* begins) {
   if (t->grp) throw HipFail{"rt_tracer_join_group: already a member of a group"};
   uint32_t r0 = 0, rn = 0;
-  band_rows(t->H, n_ranks, rank, r0, rn);
+  if (begins) {
+    if (begins[0] != 0u || begins[n_ranks] != t->H) throw HipFail{"rt_tracer_join_group_bands: the bands must cover rows 0 .. full_height"};
+    for (uint32_t k = 0; k < n_ranks; ++k) if (begins[k + 1] <= begins[k]) throw HipFail{"rt_tracer_join_group_bands: empty or descending band"};
+    r0 = begins[rank]; rn = begins[rank + 1] - begins[rank];
+  } else {
+    band_rows(t->H, n_ranks, rank, r0, rn);
+  }
   if (!t->band_mode && n_ranks > 1u) throw HipFail{"rt_tracer_join_group: the tracer must own a row band (rt_options.full_height)"};
   if (r0 != t->row0 || rn != t->rows)
     throw HipFail{fmt("rt_tracer_join_group: rank %u of %u owns rows [%u, %u) of %u, the tracer has [%u, %u)", rank, n_ranks, r0,
@@ -336,7 +372,8 @@ void member_join(rt_tracer* t, uint32_t n_ranks, uint32_t rank, const uint8_t id
   g->self_rccl = env_on("RT_MI355X_GATHER_SELF");
   for (uint32_t k = 0; k < n_ranks; ++k) {
     GroupBand gb;
-    band_rows(t->H, n_ranks, k, gb.row0, gb.rows);
+    if (begins) { gb.row0 = begins[k]; gb.rows = begins[k + 1] - begins[k]; }
+    else band_rows(t->H, n_ranks, k, gb.row0, gb.rows);
     gb.rank = static_cast<int>(k);
     gb.tracer = k == rank ? t : nullptr;
     g->bands.push_back(gb);

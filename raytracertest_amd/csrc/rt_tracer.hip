@@ -1304,7 +1304,61 @@ int rt_tracer_join_group(rt_tracer* t, uint32_t n_ranks, uint32_t rank, const ui
   std::lock_guard<std::mutex> lk(t->api_mu);
   return guarded(t, [&] {
     t->cancel_and_join();
-    member_join(t, n_ranks, rank, id ? id : zero_id);
+    member_join(t, n_ranks, rank, id ? id : zero_id, nullptr);
+  });
+}
+
+int rt_tracer_join_group_bands(rt_tracer* t, uint32_t n_ranks, uint32_t rank, const uint8_t id[RT_GROUP_ID_BYTES],
+                               const uint32_t* row_begin) {
+  if (!t || t->mg || n_ranks == 0u || rank >= n_ranks || (!id && n_ranks > 1u) || !row_begin) return RT_ERR_INVALID;
+  static const uint8_t zero_id[RT_GROUP_ID_BYTES] = {0};
+  std::lock_guard<std::mutex> lk(t->api_mu);
+  return guarded(t, [&] {
+    t->cancel_and_join();
+    member_join(t, n_ranks, rank, id ? id : zero_id, row_begin);
+  });
+}
+
+int rt_balance_rows(uint32_t n_bands, const uint32_t* row_begin, const double* cost, uint32_t granule, uint32_t* new_row_begin) {
+  if (n_bands == 0u || !row_begin || !cost || !new_row_begin) return RT_ERR_INVALID;
+  for (uint32_t k = 0; k < n_bands; ++k) if (row_begin[k + 1] <= row_begin[k]) return RT_ERR_INVALID;
+  balance_rows(n_bands, row_begin, cost, granule, new_row_begin);
+  return RT_OK;
+}
+
+int rt_tracer_set_band(rt_tracer* t, uint32_t row_begin, uint32_t rows) {
+  if (!t || t->mg || rows == 0u) return RT_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(t->api_mu);
+  return guarded(t, [&] {
+    t->cancel_and_join();
+    if (t->grp) throw HipFail{"rt_tracer_set_band: leave the group first"};
+    if (!t->band_mode) throw HipFail{"rt_tracer_set_band: the tracer owns a whole image, not a band (rt_options.full_height)"};
+    if (static_cast<uint64_t>(row_begin) + rows > t->H) throw HipFail{"row band exceeds full_height"};
+    t->use_device();
+    t->reshape(t->W, t->H, row_begin, rows);
+  });
+}
+
+int rt_tracer_rebalance(rt_tracer* t) {
+  if (!t || !t->mg) return RT_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(t->api_mu);
+  return guarded(t, [&] {
+    t->cancel_and_join();
+    multi_sync_all(t);
+    MultiState& m = *t->mg;
+    const uint32_t n = static_cast<uint32_t>(m.bands.size());
+    std::vector<uint32_t> begins(n + 1u), fresh(n + 1u);
+    std::vector<double> cost(n);
+    for (uint32_t k = 0; k < n; ++k) {
+      begins[k] = m.group.bands[k].row0;
+      std::lock_guard<std::mutex> tl(m.bands[k]->time_mu);
+      cost[k] = m.bands[k]->kernel_launches ? m.bands[k]->kernel_ms / static_cast<double>(m.bands[k]->kernel_launches) : 0.0;
+    }
+    begins[n] = t->H;
+    for (uint32_t k = 0; k < n; ++k) if (!(cost[k] > 0.0)) throw HipFail{"rt_tracer_rebalance: no timed launch on every band yet"};
+    balance_rows(n, begins.data(), cost.data(), 8u, fresh.data());
+    if (fresh == begins) return;
+    multi_resize(t, t->W, t->H, fresh.data());
   });
 }
 

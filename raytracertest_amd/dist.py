@@ -131,14 +131,17 @@ class NativeExchange:
     """The product exchange of one-process-per-GPU jobs: the band tracer joins the library's group
     (rt_tracer_join_group, RCCL); from then on every emitting TraceEnqueue/Launch carries its own gather."""
 
-    def attach(self, job):
+    def attach(self, job, row_begin=None):
         uid = [None]
         if job.rank == 0 and job.world > 1:
             from .api import group_unique_id
             uid[0] = group_unique_id()
         if job.world > 1:
             job.dist.broadcast_object_list(uid, src=0)      # 128 bytes through the launcher's rendezvous
-        job.tracer.JoinGroup(job.world, job.rank, uid[0])
+        job.tracer.JoinGroup(job.world, job.rank, uid[0], row_begin=row_begin)
+
+    def detach(self, job):
+        job.tracer.LeaveGroup()
 
     def after_emit(self, job):
         pass                                                # the library enqueued the gather behind the launch
@@ -248,6 +251,30 @@ class RowBandJob:
         t = torch.tensor([int(v)], dtype=torch.int32)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return int(t.item())
+
+    # ---- load balance (strong scaling of scenes whose cost is not uniform over the rows) ------------
+    def rebalance(self):
+        """Re-partition the rows so that every band costs the same, from the bands' kernel times since the last
+        KernelTime reset (collective in a multi-rank job).  Buffers and RNG states of the bands are re-created, as
+        by Resize; the image of a Trace does not depend on the partition.  Returns the rows per band."""
+        if self.world == 1:
+            if self.parts > 1:
+                self.tracer.Rebalance()
+            return [b["rows"] for b in self.tracer.Bands()]
+        import torch
+        from .api import balance_rows
+        ms, n = self.tracer.KernelTime(reset=True)
+        mine = torch.tensor([ms / max(n, 1), float(self.row0), float(self.rows)], dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(every, mine)
+        begins = [int(t[1].item()) for t in every] + [self.full_height]
+        fresh = balance_rows(begins, [float(t[0].item()) for t in every], 8)
+        if fresh != begins:
+            self.exchange.detach(self)
+            self.row0, self.rows = fresh[self.rank], fresh[self.rank + 1] - fresh[self.rank]
+            self.tracer.SetBand(self.row0, self.rows)
+            self.exchange.attach(self, row_begin=fresh)
+        return [fresh[k + 1] - fresh[k] for k in range(self.world)]
 
     # ---- bench plumbing ----------------------------------------------------------------------
     def barrier(self):

@@ -12,8 +12,11 @@ import numpy as np
 
 
 class HostStagedExchange:
-    def attach(self, job):
+    def attach(self, job, row_begin=None):
         self._frame = None
+
+    def detach(self, job):
+        pass
 
     def after_emit(self, job):
         import torch

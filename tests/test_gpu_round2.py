@@ -321,3 +321,33 @@ def test_adversarial_boundary_campaign_default_kernel_equals_plain_full_scan(rt)
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_boundaries.py"), "300", "777", "0.04"],
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "300 configurations, 0 mismatches" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_rebalanced_partition_gives_the_same_frame(rt, orc):
+    """rt_tracer_rebalance / rt_tracer_set_band + rt_tracer_join_group_bands: an uneven, cost-balanced partition (rows in
+    multiples of 8) leaves the frame bit-identical -- the RNG streams are keyed by the global pixel index."""
+    from raytracertest_amd import scenes
+    rng = np.random.default_rng(3)
+    tri = np.concatenate([rng.uniform(-2, 2, (600, 1, 2)), rng.uniform(-6, -2, (600, 1, 1))], axis=2) + rng.uniform(-0.3, 0.3, (600, 3, 3))
+    tri[:, :, 1] = tri[:, :, 1] * 0.3 + 1.0               # everything in the upper part of the picture: uneven bands
+    scn = scenes._tri_rows(tri.astype(np.float32))
+    W, H = 96, 160
+    g, o = pair(rt, orc, W, H, scn, devices=[0] * 4)
+    g.TraceEnqueue(2, 2); g.TraceEnqueue(2, 2); g.Sync()
+    before = [b["rows"] for b in g.Bands()]
+    g.Rebalance()
+    after = g.Bands()
+    assert sum(b["rows"] for b in after) == H and all(b["rows"] % 8 == 0 for b in after[:-1]) and before == [40] * 4
+    g.Trace(2, 3, 0); assert g.Wait()                   # (Rebalance re-created the RNG states, like Resize)
+    o.trace(2, 3)
+    assert_frame_equal(g, o)
+    g.close()
+    assert rt.balance_rows([0, 270, 540, 810, 1080], [1.0, 3.0, 3.0, 1.0]) == [0, 360, 544, 720, 1080]
+    # the multi-process form of the same move on one rank: another band of the frame, explicit partition
+    b = rt.RayTracer((W, 40), (0, 0, 0), (0.0, 0.0), 70.0, 3.0, 0.05, seed=3, full_height=H, row_begin=0)
+    assert b.UploadScene(scn)
+    b.SetBand(0, H)
+    b.JoinGroup(1, 0, None, row_begin=[0, H])
+    b.TraceEnqueue(2, 3); b.Sync()
+    assert np.array_equal(b.Frame(), o.image)
+    b.close()
