@@ -72,6 +72,9 @@ struct Group {
   hipEvent_t frame_free[2] = {nullptr, nullptr};   // root: the consumer of frame b (host copy) has finished
   bool frame_free_valid[2] = {false, false};
   int next_b = 0, last_b = -1;
+  // gather() runs on whoever drives the frames (render thread, or an API thread under the handle's api_mu);
+  // sync() and the timing read-out may come from any thread meanwhile: mu serialises them
+  std::mutex mu;
   // gather timing (root): event pairs on the root's gather stream around the exchange
   struct Timed { hipEvent_t a, b; };
   std::vector<Timed> timed_pending, timed_free;
@@ -174,6 +177,7 @@ struct Group {
   // The exchange of frame b, enqueued on the gather streams behind every local tile: grouped
   // ncclSend (owners) / ncclRecv (root) of the travelling bands, one group for all local ranks.
   void gather(int b) {
+    std::lock_guard<std::mutex> lk(mu);
     for (GatherRank& r : local) {
       HIP_CHECK(hipSetDevice(r.device));
       for (GroupBand& band : bands)
@@ -235,11 +239,18 @@ struct Group {
   }
 
   void sync() {                     // every gather stream of this process
+    std::lock_guard<std::mutex> lk(mu);
     for (GatherRank& r : local) {
       HIP_CHECK(hipSetDevice(r.device));
       HIP_CHECK(hipStreamSynchronize(r.gstream));
     }
     if (has_root) { HIP_CHECK(hipSetDevice(local[0].device)); reap_timed(true); }
+  }
+  void read_time(double* total_ms, uint64_t* n, bool reset) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (total_ms) *total_ms = gather_ms;
+    if (n) *n = gathers;
+    if (reset) { gather_ms = 0.0; gathers = 0; }
   }
 };
 

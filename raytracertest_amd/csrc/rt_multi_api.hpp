@@ -18,8 +18,9 @@ void multi_sync_all(rt_tracer* t) {
   MultiState& m = *t->mg;
   for (rt_tracer* b : m.bands) {
     b->use_device();
+    const uint64_t seen = b->event_seq_now();        // a running render thread may enqueue more meanwhile
     HIP_CHECK(hipStreamSynchronize(b->main_stream()));
-    b->drain_events();
+    b->drain_events_before(seen);
   }
   m.group.sync();
 }

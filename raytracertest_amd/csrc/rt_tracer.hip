@@ -1374,9 +1374,9 @@ int rt_tracer_leave_group(rt_tracer* t) {
 int rt_tracer_gather_time(rt_tracer* t, double* total_ms, uint64_t* gathers, int reset_after) {
   if (!t) return RT_ERR_INVALID;
   Group* g = t->mg ? &t->mg->group : t->grp;
-  if (total_ms) *total_ms = g ? g->gather_ms : 0.0;
-  if (gathers) *gathers = g ? g->gathers : 0u;
-  if (g && reset_after) { g->gather_ms = 0.0; g->gathers = 0; }
+  if (total_ms) *total_ms = 0.0;
+  if (gathers) *gathers = 0u;
+  if (g) g->read_time(total_ms, gathers, reset_after != 0);
   return RT_OK;
 }
 
