@@ -213,3 +213,49 @@ def test_row_band_job_over_two_ranks_with_an_oracle_backed_tracer(tmp_path, orc,
     whole.trace(5, 1)
     assert np.array_equal(r["final"], whole.image)
     assert r["launches"].tolist() == [3, 2]        # fuse = 4: iterations 0..2 (update at 2), 3..4 (update at 4 = the end)
+
+
+# ---------------------------------------------------------------- the product exchange's host logic (id hand-out, re-partition)
+def _native_exchange_worker(rank, world, port, outdir):
+    import sys, json
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from raytracertest_amd import api, scenes
+    from raytracertest_amd.dist import RowBandJob, NativeExchange
+    api.group_unique_id = lambda: bytes(range(128))          # (RCCL itself needs a device; rank 0's id is what travels)
+    log = []
+
+    class FakeTracer:                                        # records what the job asks of the library
+        def __init__(self, row0, rows): self.row0, self.rows = row0, rows
+        def UploadScene(self, t): return True
+        def UploadSpheres(self, s): pass
+        def JoinGroup(self, n, r, uid, row_begin=None): log.append(("join", n, r, uid.hex() if uid else None, row_begin))
+        def LeaveGroup(self): log.append(("leave",))
+        def SetBand(self, row0, rows): log.append(("band", row0, rows)); self.row0, self.rows = row0, rows
+        def KernelTime(self, reset=True): return (2.0 if rank == 0 else 6.0), 2     # rank 1's band is three times as expensive
+        def close(self): pass
+
+    cfg = dict(width=16, height=64, iterations=1, samples=1, angles=(0.0, 0.0), fov=70.0, focal=3.0, aperture=0.05, seed=1)
+    job = RowBandJob(cfg, scenes.cornell32(), np.zeros((0, 4), np.float32), world=world, rank=rank, local_rank=rank, weak=False,
+                     exchange=NativeExchange(),
+                     tracer_factory=lambda device=0, full_height=0, row_begin=0, **kw: FakeTracer(row_begin, full_height // world))
+    rows = job.rebalance()
+    json.dump({"log": log, "rows": rows, "mine": [job.row0, job.rows]}, open(os.path.join(outdir, "ex%d.json" % rank), "w"))
+    job.close()
+
+
+@pytest.mark.timeout(300)
+def test_native_exchange_hands_out_the_id_and_rebalances_consistently(tmp_path):
+    """NativeExchange / RowBandJob.rebalance on two gloo ranks with a recording stand-in for the tracer: every rank joins
+    with rank 0's 128-byte id; after the bands' times were exchanged all ranks leave, move to the SAME new partition
+    (multiples of 8 rows, more rows for the cheaper band) and re-join with it."""
+    import json
+    import torch.multiprocessing as mp
+    mp.spawn(_native_exchange_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r = [json.load(open(os.path.join(str(tmp_path), "ex%d.json" % k))) for k in range(2)]
+    uid = bytes(range(128)).hex()
+    for k in range(2):
+        assert r[k]["log"][0] == ["join", 2, k, uid, None]
+        assert r[k]["log"][1] == ["leave"] and r[k]["log"][2][0] == "band"
+        assert r[k]["log"][3] == ["join", 2, k, uid, [0, 40, 64]]
+    assert r[0]["rows"] == r[1]["rows"] == [40, 24] and r[0]["mine"] == [0, 40] and r[1]["mine"] == [40, 24]
