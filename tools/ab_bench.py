@@ -20,11 +20,15 @@ g = R.RayTracer((cfg["width"], cfg["height"]), (0, 0, 0), cfg["angles"], cfg["fo
                 seed=cfg["seed"], samples_in_flight=%(k)d, lds_chunk=%(chunk)d, no_filter=%(nofilter)r, no_binning=%(nobin)r, bin_list=%(binlist)d)
 if tris.shape[0]: g.UploadScene(tris)
 if sph.shape[0]: g.UploadSpheres(sph)
+import time
+if %(cold)r: g.SetListReuse(False)             # bench.py's headline mode: every step classifies afresh
 for _ in range(%(warmup)d): g.TraceEnqueue(1, cfg["samples"])
 g.Sync(); g.KernelTime()
+t0 = time.perf_counter()
 for _ in range(%(steps)d): g.TraceEnqueue(1, cfg["samples"])
-g.Sync(); ms, n = g.KernelTime()
-print(json.dumps({"us": ms / n * 1e3, "info": g.Info()}))
+g.Sync(); wall = (time.perf_counter() - t0) / %(steps)d * 1e6
+ms, n = g.KernelTime()
+print(json.dumps({"us": ms / n * 1e3, "wall_us": wall, "info": g.Info()}))
 '''
 
 
@@ -40,28 +44,32 @@ def main():
     for v in a.variants:
         name, rest = v.split("=", 1)
         parts = rest.split(",")
-        opts = {"lib": parts[0], "k": 0, "chunk": 0, "nofilter": False, "nobin": False, "binlist": 0}
+        opts = {"lib": parts[0], "k": 0, "chunk": 0, "nofilter": False, "nobin": False, "binlist": 0, "cold": False}
         for p in parts[1:]:
             key, val = p.split("=")
-            opts[key] = (val == "1") if key in ("nofilter", "nobin") else int(val)
+            opts[key] = (val == "1") if key in ("nofilter", "nobin", "cold") else int(val)
         variants.append((name, opts))
     res = {n: [] for n, _ in variants}
+    wall = {n: [] for n, _ in variants}
     for _ in range(a.rounds):
         for name, o in variants:
             env = dict(os.environ)
             lib = o["lib"]
             env["RT_MI355X_LIB"] = lib if os.path.isabs(lib) else os.path.join(ROOT, "raytracertest_amd", "lib", lib)
             code = CHILD % dict(root=ROOT, config=a.config, k=o["k"], chunk=o["chunk"], nofilter=o["nofilter"], nobin=o["nobin"], binlist=o["binlist"],
-                                warmup=a.warmup, steps=a.steps)
+                                cold=o["cold"], warmup=a.warmup, steps=a.steps)
             out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
             if out.returncode != 0:
                 print(name, "FAILED", out.stderr[-400:])
                 continue
-            res[name].append(json.loads(out.stdout.strip().splitlines()[-1])["us"])
+            line = json.loads(out.stdout.strip().splitlines()[-1])
+            res[name].append(line["us"]); wall[name].append(line["wall_us"])
     for name, _ in variants:
         v = sorted(res[name])
         if v:
-            print("%-22s min %10.1f us  median %10.1f us  (%s)" % (name, v[0], v[len(v) // 2], ", ".join("%.1f" % x for x in res[name])))
+            w = sorted(wall[name])
+            print("%-22s kernel min %9.1f median %9.1f us | step wall min %9.1f median %9.1f us  (%s)"
+                  % (name, v[0], v[len(v) // 2], w[0], w[len(w) // 2], ", ".join("%.1f" % x for x in wall[name])))
 
 
 if __name__ == "__main__":
