@@ -593,9 +593,6 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
 #else
   auto tl_mark = [](uint32_t) {};
 #endif
-#if defined(RT_EXP_PRIO) && RT_EXP_PRIO == 1
-  __builtin_amdgcn_s_setprio(2);                                   // experiment: young waves (prologue) first
-#endif
   Rng rng;                                                         // :131
   rng.d = p.rng[0 * static_cast<size_t>(p.npix) + pix];
   rng.v0 = p.rng[1 * static_cast<size_t>(p.npix) + pix];
@@ -841,11 +838,6 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
     forms_ready = pretest && list_complete;
   }
   tl_mark(1);                                                      // family + classification done
-#if defined(RT_EXP_PRIO) && RT_EXP_PRIO == 1
-  __builtin_amdgcn_s_setprio(0);
-#elif defined(RT_EXP_PRIO) && RT_EXP_PRIO == 2
-  __builtin_amdgcn_s_setprio(2);                                   // experiment: waves in the sample loop first
-#endif
   const uint32_t iters = FUSE ? p.iters : 1u;
   float rx = 0.0f, ry = 0.0f, rz = 0.0f, rw = 0.0f;                // FUSE: the pixel's RenderBuffer value so far
   uint32_t cnt_first = 0u;
