@@ -47,6 +47,8 @@ extern "C" {
 
 #define RT_FLAG_NO_MACRO_BINS 16u /* disable the macro-tile level of the classification (large scenes): every block
                                   pre-culls the whole triangle list (debug / parity tests / A-B) */
+#define RT_FLAG_NO_SURE_HIT 32u /* small scenes: run the intersection tests also on tiles whose candidate list is one triangle that
+                                  every ray of the tile certainly hits (debug / parity tests / A-B; the result is the same) */
 #define RT_FLAG_SMOOTH_NORMALS 8u /* shading extension for scenes uploaded with rt_tracer_upload_scene_edges: the
                                   colour is |normalize(w*n0 + u*n1 + v*n2)|, the rows' packed vertex normals
                                   interpolated at the hit (w = (1-u)-v), instead of |face normal| (Kernels.cuh:97-99).
@@ -180,7 +182,9 @@ int  rt_tracer_kernel_time(rt_tracer* t, double* total_ms, uint64_t* launches, i
  *             (culling), B (u), C (v), and pairs that reached the exact stage D;
  *   out[8]    candidate triangles kept by the per-tile classification, summed over waves and
  *             rounds; out[9] classification rounds (one per wave when its list fits in LDS).
- *   out[10..15] reserved. */
+ *   out[10]   large scenes: candidate tests of a sample batch skipped by the per-sample forms; small scenes: sample
+ *             batches of tiles that skipped their tests because the one candidate is certainly hit;
+ *   out[11..15] reserved. */
 int  rt_tracer_trace_stats(rt_tracer* t, uint32_t samples, uint64_t out[16]);
 /* Copy one of the tracer's device buffers to host memory / to another device pointer. */
 int  rt_tracer_read_buffer(rt_tracer* t, int which, void* dst, size_t bytes);

@@ -59,6 +59,8 @@ constexpr uint32_t TRACE_LISTS_STORE = 8u;
 constexpr uint32_t TRACE_LISTS_LOAD = 16u;
 // large-scene kernels: per-sample conservative forms per candidate (9 more floats per LDS record)
 constexpr uint32_t TRACE_PRETEST = 32u;
+// small-scene kernels: do not skip the intersection tests of tiles whose list is one certainly-hit triangle (A/B, tests)
+constexpr uint32_t TRACE_NO_SURE_HIT = 64u;
 
 // jump: J^(2^k), k < 32, 160 columns x 8 words; win: the 4-bit window tables of J^(2^m), m < 6 (rt_rng_host.hpp)
 hipError_t launch_rng_init(uint32_t* rng, uint32_t npix, uint32_t p0, const uint32_t seeded[6],

@@ -367,8 +367,21 @@ __device__ __forceinline__ TileFamily make_family(const TraceParams& p, const Fo
 // of a sample batch are such wave-wide misses (the candidate list covers the whole lens, one
 // batch only 256 points of it).
 // true = every ray of the family certainly misses this triangle (see the block comment)
-template <bool FORMS = false>
-__device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0, V3 e1, V3 e2, float* forms = nullptr) {
+// SURE (small-scene kernels): *sure_hit = every ray of the family certainly HITS this triangle in the
+// reference's own arithmetic -- the mirror image of the drop rules, from the same interval ends.  With det_lo,
+// U_lo, V_lo, U_hi + V_hi the ends that already contain the rounding allowance of the reference's evaluation,
+//     det_lo > 1.0001 eps lmax          not culled (:42): det >= det'_lo / |w| > eps
+//     U_lo >= 1e-4 det_hi (> 0)         u = fl(U * fl(1/det)) >= 0 (:51), product of two positive numbers
+//     V_lo >= 1e-4 det_hi               v >= 0 (:58)
+//     U_hi + V_hi <= 0.9999 det_lo      u + v <= 0.9999 (1 + 4 ulp) < 1, hence also u <= 1 (:51,:58)
+//     |e2|.|tv x e1| lmax < 1e37 det_lo t = dot(e2, qv) * inv (:63) is finite, so -FLT_MAX < t records the hit (:84)
+// Any NaN makes a comparison false -> not sure.  A tile whose candidate list is exactly ONE such triangle needs no
+// intersection arithmetic at all under the reference's flat shading (Kernels.cuh:95-99 uses the winner's vertices
+// only, `hitpoint` is unused): every sample's winner is that triangle.  (Not with spheres, smooth normals or the
+// nearest-hit rule, which need t, u, v.)
+template <bool FORMS = false, bool SURE = false>
+__device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0, V3 e1, V3 e2, float* forms = nullptr,
+                                                     bool* sure_hit = nullptr) {
   // rounding allowance relative to the magnitude sums (DESIGN.md 4.1 "Rounding budget": <= ~20 half-ulps are
   // needed, 67 / 84 are charged).  RT_BIN_SLACK_SCALE exists for the teeth test of the adversarial campaign only
   // (tools/stress_boundaries.py against a build with the allowance scaled down must FIND mismatches).
@@ -390,6 +403,7 @@ __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0,
   }
   float detc = 0.0f, det_rad = 0.0f, Uc = 0.0f, U_rad = 0.0f, Vc = 0.0f, V_rad = 0.0f;
   float DR = 0.0f, UR = 0.0f, VR = 0.0f;                            // FORMS: radii for a known origin
+  float tmag = 0.0f;                                                // SURE: >= |dot(e2, (o - v0) x e1)|
   float Nv[3] = {0.0f, 0.0f, 0.0f}, Gu[3] = {0.0f, 0.0f, 0.0f}, Gv[3] = {0.0f, 0.0f, 0.0f};
   float Eu[3] = {0.0f, 0.0f, 0.0f}, Ev[3] = {0.0f, 0.0f, 0.0f}, qd[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -414,6 +428,7 @@ __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0,
     U_rad += a[i] * (__builtin_fabsf(Gxe2) + rxe2) + r[i] * __builtin_fabsf(e2xt) + c * (T[i] * Wxe2 + a[i] * Gabs);
     Vc += wc[i] * txe1;
     V_rad += a[i] * __builtin_fabsf(e1xG) + r[i] * (__builtin_fabsf(txe1) + axe1) + c * (W[i] * Txe1 + a[i] * Gabs);
+    if constexpr (SURE) tmag += E2[i] * Txe1;
     if constexpr (FORMS) {
       // a_r: what is left of |do_i| once the sample's own origin is used -- the roundings of o = pos + off
       // and of o - v0 (the aperture part A of orad is the known do itself)
@@ -458,6 +473,11 @@ __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0,
   const float det_hi = detc + det_rad;
   const float U_lo = Uc - U_rad, U_hi = Uc + U_rad, V_lo = Vc - V_rad, V_hi = Vc + V_rad;
   const float neg = det_hi * -1e-6f, big = det_hi * 1.0002f;
+  if constexpr (SURE) {
+    const float det_lo = detc - det_rad;
+    *sure_hit = (det_lo > (RT_EPS * 1.0001f) * f.lmax) && (U_lo >= 1e-4f * det_hi) && (V_lo >= 1e-4f * det_hi) &&
+                ((U_hi + V_hi) <= 0.9999f * det_lo) && (tmag * f.lmax < 1e37f * det_lo);
+  }
   const bool all_culled = det_hi < RT_EPS * f.lmin;
   const bool pos = det_hi > 0.0f;
   const bool out = pos && ((U_hi < neg) || (U_lo > big) || (V_hi < neg) || ((U_lo + V_lo) > big));
@@ -646,6 +666,11 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   TileFamily fam;
   bool list_complete = false;       // the list in LDS covers the whole scene (classification done once)
   uint32_t list_count = 0;
+  // ONEPASS: the tile's list is exactly one triangle that every ray of the family certainly hits (wave-uniform):
+  // the sample loop then skips the intersection tests -- the winner is known (tile_misses_triangle<.., SURE>)
+  bool sure_hit_tile = false;
+  uint32_t sure_kept = 0;
+  const bool sure_ok = BIN && ONEPASS && (p.flags & (TRACE_NEAREST_HIT | TRACE_NO_SURE_HIT)) == 0u && p.n_spheres == 0u && p.tri_n == nullptr;
   // Block-level pre-cull (scenes larger than the per-wave list): the 256 threads classify every
   // triangle ONCE against the union of the block's four tile families and keep the survivors'
   // indices, in ascending order, in LDS; each wave then only refines that short list against its
@@ -757,6 +782,10 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
         if constexpr (PRETEST && WF) {
           if (pretest) keep = valid && !tile_misses_triangle<true>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z}, forms);
           else keep = valid && !tile_misses_triangle(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z});
+        } else if constexpr (ONEPASS) {
+          bool sure = false;
+          keep = valid && !tile_misses_triangle<false, true>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z}, nullptr, &sure);
+          sure_kept += static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(keep && sure)));
         } else {
           keep = valid && !tile_misses_triangle(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z});
         }
@@ -804,7 +833,9 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
     uint32_t* const saved = p.tile_lists + slot * (1u + L);
     if (p.flags & TRACE_LISTS_LOAD) {
       // wave-uniform by construction; readfirstlane tells the compiler (scalar loop control below)
-      const uint32_t count = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(saved[0])));
+      const uint32_t word = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(saved[0])));
+      const uint32_t count = word & 0x7FFFFFFFu;                     // bit 31: the stored list is ONE certainly-hit triangle
+      sure_hit_tile = sure_ok && (word >> 31) != 0u;
       for (uint32_t base = 0; base < count; base += 64u) {
         const uint32_t e = base + lane;
         if (e < count) {
@@ -820,8 +851,10 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
       list_count = count;
     } else {
       (void)classify(0u, std::false_type{});
+      const bool sure_one = list_count == 1u && sure_kept == 1u;       // (independent of the launch's flags: stored as such)
+      sure_hit_tile = sure_ok && sure_one;
       if (p.flags & TRACE_LISTS_STORE) {
-        if (lane == 0u) saved[0] = list_count;
+        if (lane == 0u) saved[0] = list_count | (sure_one ? 0x80000000u : 0u);
         for (uint32_t e = lane; e < list_count; e += 64u) saved[1u + e] = static_cast<uint32_t>(cI[e]);
       }
     }
@@ -865,6 +898,12 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
       dFx = focal.x - fam.fc[0]; dFy = focal.y - fam.fc[1]; dFz = focal.z - fam.fc[2];
     }
     if constexpr (BIN && ONEPASS) {
+      if (sure_hit_tile) {                                         // wave-uniform: the one candidate wins every sample
+        const int only = cI[0];
+#pragma unroll
+        for (int k = 0; k < K; ++k) best_i[k] = only;
+        if constexpr (STATS) st_pre += 1;
+      } else
       for (uint32_t j = 0; j < list_count; ++j) {                  // ascending triangle order
         const float4 A0 = cA[2u * j], A1 = cA[2u * j + 1u];
         test_triangle<FMA, K, FILTER, STATS>(A0, A1, [&] { return cB[j]; }, cI[j], o, d, best_t, best_i,

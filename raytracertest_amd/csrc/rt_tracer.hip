@@ -323,6 +323,12 @@ struct rt_tracer {
     return p;
   }
 
+  // the launch-independent TRACE_* flags of this tracer
+  uint32_t mode_flags(const rtk::TraceParams& p) const {
+    return (nearest_hit ? rtk::TRACE_NEAREST_HIT : 0u) | (p.pretest_on ? rtk::TRACE_PRETEST : 0u) |
+           (sure_hit ? 0u : rtk::TRACE_NO_SURE_HIT);
+  }
+
   int pick_k(uint32_t samples) const {
     if (k_req == 1 || k_req == 2 || k_req == 4) return static_cast<int>(k_req);
     // K samples of a pixel in registers per pass.  4 amortises the LDS record reads on long
@@ -353,7 +359,7 @@ struct rt_tracer {
     rtk::TraceParams p = params(samples);
     p.iters = iters;
     p.image_host = host_image;
-    p.flags = flags | (nearest_hit ? rtk::TRACE_NEAREST_HIT : 0u) | (p.pretest_on ? rtk::TRACE_PRETEST : 0u);
+    p.flags = flags | mode_flags(p);
     p.image = d_image;
     const uint32_t list_flags = decide_tile_lists(p, (flags & rtk::TRACE_ZERO_ACC) != 0u);
     last_k = K; last_chunk = p.chunk;
@@ -539,6 +545,7 @@ struct rt_tracer {
   size_t macro_lists_words[2] = {0, 0};
   bool macro = true;                  // RT_FLAG_NO_MACRO_BINS / RT_MI355X_NO_MACRO=1 turn it off
   bool pretest = true;                // RT_MI355X_NO_PRETEST=1 turns the per-sample forms off
+  bool sure_hit = true;               // RT_FLAG_NO_SURE_HIT / RT_MI355X_NO_SUREHIT=1: tiles of one certainly-hit triangle run the tests anyway
   // Stored tile candidate lists (small scenes) survive from one Trace to the next while camera, lens, scene,
   // frame and arithmetic mode are unchanged -- like any acceleration structure that is rebuilt only when its
   // inputs change.  rt_tracer_set_list_reuse(t, 0) restricts the reuse to the launches of one Trace.
@@ -826,6 +833,7 @@ int rt_tracer_create_ex(const uint32_t imageSize[2], const float cameraPosition[
   t->nearest_hit = (opt.flags & RT_FLAG_NEAREST_HIT) != 0;
   t->smooth_normals = (opt.flags & RT_FLAG_SMOOTH_NORMALS) != 0;
   { const char* np = getenv("RT_MI355X_NO_PRETEST"); t->pretest = !(np && np[0] == '1'); }
+  { const char* nh = getenv("RT_MI355X_NO_SUREHIT"); t->sure_hit = (opt.flags & RT_FLAG_NO_SURE_HIT) == 0 && !(nh && nh[0] == '1'); }
   { const char* ns = getenv("RT_MI355X_NO_SPLIT"); t->split_launches = !(ns && ns[0] == '1'); }
   if (const char* es = getenv("RT_MI355X_EVENT_STRIDE")) t->event_stride = static_cast<uint32_t>(strtoul(es, nullptr, 10));
   {
@@ -1188,7 +1196,7 @@ int rt_tracer_trace_stats(rt_tracer* t, uint32_t samples, uint64_t out[16]) {
     t->clear_accumulators();
     rtk::TraceParams p = t->params(samples);
     p.stats = counters.as<unsigned long long>();
-    p.flags = (t->nearest_hit ? rtk::TRACE_NEAREST_HIT : 0u) | (p.pretest_on ? rtk::TRACE_PRETEST : 0u);
+    p.flags = t->mode_flags(p);
     t->attach_macro_lists(p, 0, t->main_stream());
     HIP_CHECK(rtk::launch_trace(p, t->fma, t->filter, t->bin, t->pick_k(samples), t->main_stream()));
     HIP_CHECK(hipStreamSynchronize(t->main_stream()));
@@ -1477,7 +1485,7 @@ extern "C" int rt_dbg_trace_timeline(rt_tracer* t, uint32_t samples, unsigned lo
     DevBuf buf(words * sizeof(unsigned long long));
     HIP_CHECK(hipMemsetAsync(buf.p, 0, words * sizeof(unsigned long long), t->main_stream()));
     rtk::TraceParams p = t->params(samples);
-    p.flags = rtk::TRACE_ZERO_ACC | rtk::TRACE_EMIT_IMAGE | (t->nearest_hit ? rtk::TRACE_NEAREST_HIT : 0u) | (p.pretest_on ? rtk::TRACE_PRETEST : 0u);
+    p.flags = rtk::TRACE_ZERO_ACC | rtk::TRACE_EMIT_IMAGE | t->mode_flags(p);
     p.image = t->d_image;
     p.timeline = buf.as<unsigned long long>();
     t->attach_macro_lists(p, 0, t->main_stream());

@@ -17,6 +17,9 @@ tile-corner pixels, lens samples on the rim of the aperture or at its centre -- 
             triangle pointing away from the tile -- every other ray of the tile misses, the corner ray sits on
             u = v = 0; small and far (|e| down to 1e-5 of the distance), where the reference's own evaluation
             of u, v is dominated by rounding (error ~ 10 ulp * distance / size);
+  cover     contains the whole footprint of a tile's family (the four corner pixels' rays, lens rim included) with a
+            margin of 0, 1e-6, 1e-4, 1e-2 or 1 of its size: the "certainly hit" verdict (tiles whose one candidate
+            needs no intersection test) decides just inside / just outside its own boundary;
   filler    plain random triangles around all of that (candidate lists of realistic length),
 
 at coordinate scales 1e-3 ... 1e4 and apertures from 0 to many times the scene.  The camera math below is a
@@ -87,7 +90,7 @@ def _pick_ray(rng, cam, W, H):
 def adversarial_triangles(rng, cam, W, H, n, scale):
     """(n, 3, 3) float32 triangles around the rays of the camera's tile families (see the module docstring)."""
     tris = np.zeros((n, 3, 3), np.float64)
-    kinds = rng.choice(6, n, p=[0.2, 0.2, 0.1, 0.1, 0.15, 0.25])
+    kinds = rng.choice(7, n, p=[0.18, 0.18, 0.09, 0.1, 0.1, 0.23, 0.12])
     jitter = rng.choice([0, 1, 2, 4, 16, 64], n, p=[0.15, 0.2, 0.2, 0.2, 0.15, 0.1])
     for i in range(n):
         o, d, focal, dc = _pick_ray(rng, cam, W, H)
@@ -133,6 +136,22 @@ def adversarial_triangles(rng, cam, W, H, n, scale):
             v1 = P + (out + side * rng.uniform(0.0, 1.5)) * size + d * size * rng.uniform(-1, 1)
             v2 = P + (out - side * rng.uniform(0.0, 1.5)) * size + d * size * rng.uniform(-1, 1)
             tris[i] = (P, v1, v2) if rng.integers(0, 2) else (v1, v2, P)
+        elif k == 6:                                                  # covers the tile family's footprint at distance t, by a margin
+            tx, ty = rng.integers(0, (W + 7) // 8), rng.integers(0, (H + 7) // 8)
+            pts = []
+            for cxp, cyp in ((0, 0), (7, 0), (0, 7), (7, 7)):
+                for lens in ((1.0, 0.0), (-1.0, 0.0), (0.0, 1.0), (0.0, -1.0)):
+                    oo, dd, _ = family_ray(cam, W, H, min(W - 1, tx * 8 + cxp), min(H - 1, ty * 8 + cyp), lens)
+                    pts.append(oo + dd * t)
+            pts = np.array(pts)
+            cen = pts.mean(axis=0)
+            _, dcen, _ = family_ray(cam, W, H, tx * 8 + 3.5, ty * 8 + 3.5, (0.0, 0.0))
+            a = _perp(rng, dcen)
+            b = np.cross(dcen, a)
+            rad = max(np.sqrt(((pts - cen) @ a) ** 2 + ((pts - cen) @ b) ** 2).max(), 1e-30)
+            m = 2.0 * rad * (1.0 + float(rng.choice([0.0, 1e-6, 1e-4, 1e-2, 1.0])))     # inscribed circle of radius rad (1 + margin)
+            tilt = dcen * rad * rng.uniform(-1, 1)
+            tris[i] = (cen + a * m + tilt, cen + (-0.5 * a + 0.8660254 * b) * m, cen + (-0.5 * a - 0.8660254 * b) * m - tilt)
         else:                                                         # filler
             c = P + rng.normal(size=3) * size
             tris[i] = c + rng.uniform(-1, 1, (3, 3)) * size
