@@ -375,10 +375,10 @@ __device__ __forceinline__ TileFamily make_family(const TraceParams& p, const Fo
 //     V_lo >= 1e-4 det_hi               v >= 0 (:58)
 //     U_hi + V_hi <= 0.9999 det_lo      u + v <= 0.9999 (1 + 4 ulp) < 1, hence also u <= 1 (:51,:58)
 //     |e2|.|tv x e1| lmax < 1e37 det_lo t = dot(e2, qv) * inv (:63) is finite, so -FLT_MAX < t records the hit (:84)
-// Any NaN makes a comparison false -> not sure.  A tile whose candidate list is exactly ONE such triangle needs no
-// intersection arithmetic at all under the reference's flat shading (Kernels.cuh:95-99 uses the winner's vertices
-// only, `hitpoint` is unused): every sample's winner is that triangle.  (Not with spheres, smooth normals or the
-// nearest-hit rule, which need t, u, v.)
+// Any NaN makes a comparison false -> not sure.  A tile whose candidate list is exactly ONE such triangle needs neither
+// rays nor intersection arithmetic under the reference's flat shading (Kernels.cuh:95-99 uses the winner's vertices
+// only, `hitpoint` is unused): every sample's radiance is that triangle's colour.  Its samples keep their RNG draws
+// and their additions, nothing else.  (Not with spheres, smooth normals or the nearest-hit rule, which need t, u, v.)
 template <bool FORMS = false, bool SURE = false>
 __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0, V3 e1, V3 e2, float* forms = nullptr,
                                                      bool* sure_hit = nullptr) {
@@ -871,6 +871,8 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
     forms_ready = pretest && list_complete;
   }
   tl_mark(1);                                                      // family + classification done
+  float4 sure_col = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if constexpr (BIN && ONEPASS) { if (sure_hit_tile) sure_col = p.tri_color[cI[0]]; }
   const uint32_t iters = FUSE ? p.iters : 1u;
   float rx = 0.0f, ry = 0.0f, rz = 0.0f, rw = 0.0f;                // FUSE: the pixel's RenderBuffer value so far
   uint32_t cnt_first = 0u;
@@ -878,10 +880,26 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   if constexpr (FUSE) { ax = 0.0f; ay = 0.0f; az = 0.0f; }          // accu, :133
   for (uint32_t s0 = 0; s0 < p.samples; s0 += K) {                 // :134, K samples per pass
     if (s0 == static_cast<uint32_t>(K)) tl_mark(2);                // first batch done (includes the wait for the RNG state)
+    const uint32_t valid_k = (p.samples - s0 < static_cast<uint32_t>(K)) ? p.samples - s0 : static_cast<uint32_t>(K);
+    if constexpr (BIN && ONEPASS) {
+      // The tile's one candidate is hit by every ray of its family: every sample's radiance is that triangle's colour
+      // (Kernels.cuh:95-99), whatever the lens sample -- no ray, no test.  What a sample still does to the state is kept
+      // exactly: the three draws of its lens sample (Random.cuh:15-16) and the additions of :137 in sample order.
+      if (sure_hit_tile) {                                         // wave-uniform
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          if (static_cast<uint32_t>(k) < valid_k) {
+            (void)rtd::rng_next(rng); (void)rtd::rng_next(rng); (void)rtd::rng_next(rng);
+            ax += sure_col.x; ay += sure_col.y; az += sure_col.z;
+          }
+        }
+        if constexpr (STATS) st_pre += 1;
+        continue;
+      }
+    }
     V3 o[K], d[K];
     float best_t[K];
     int best_i[K];
-    const uint32_t valid_k = (p.samples - s0 < static_cast<uint32_t>(K)) ? p.samples - s0 : static_cast<uint32_t>(K);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       if (static_cast<uint32_t>(k) < valid_k) get_ray<FMA>(p, focal, rng, o[k], d[k]);   // :136
@@ -898,12 +916,6 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
       dFx = focal.x - fam.fc[0]; dFy = focal.y - fam.fc[1]; dFz = focal.z - fam.fc[2];
     }
     if constexpr (BIN && ONEPASS) {
-      if (sure_hit_tile) {                                         // wave-uniform: the one candidate wins every sample
-        const int only = cI[0];
-#pragma unroll
-        for (int k = 0; k < K; ++k) best_i[k] = only;
-        if constexpr (STATS) st_pre += 1;
-      } else
       for (uint32_t j = 0; j < list_count; ++j) {                  // ascending triangle order
         const float4 A0 = cA[2u * j], A1 = cA[2u * j + 1u];
         test_triangle<FMA, K, FILTER, STATS>(A0, A1, [&] { return cB[j]; }, cI[j], o, d, best_t, best_i,
