@@ -375,13 +375,20 @@ __device__ __forceinline__ TileFamily make_family(const TraceParams& p, const Fo
 //     V_lo >= 1e-4 det_hi               v >= 0 (:58)
 //     U_hi + V_hi <= 0.9999 det_lo      u + v <= 0.9999 (1 + 4 ulp) < 1, hence also u <= 1 (:51,:58)
 //     |e2|.|tv x e1| lmax < 1e37 det_lo t = dot(e2, qv) * inv (:63) is finite, so -FLT_MAX < t records the hit (:84)
-// Any NaN makes a comparison false -> not sure.  A tile whose candidate list is exactly ONE such triangle needs neither
-// rays nor intersection arithmetic under the reference's flat shading (Kernels.cuh:95-99 uses the winner's vertices
-// only, `hitpoint` is unused): every sample's radiance is that triangle's colour.  Its samples keep their RNG draws
-// and their additions, nothing else.  (Not with spheres, smooth normals or the nearest-hit rule, which need t, u, v.)
+// Any NaN makes a comparison false -> not sure.
+// WHICH hit wins (farthest, Kernels.cuh:84) is decided the same way.  The reference's t = dot(e2, (o - v0) x e1) / det
+// (:63) equals Nt |w| / det' with Nt = -(o - v0).N affine in the lens offset alone; two candidates of one ray share
+// |w|, so A is farther than j iff qA = NtA / det'A > qj = Ntj / det'j.  q[0] is a lower bound of q over the family
+// (meaningful when sure), q[1] an upper bound over the rays that may hit at all (+inf when det' may reach 0: t is
+// unbounded there); both contain the allowance c for the reference's evaluation of the numerator.
+// A tile in which one certainly-hit triangle A has qA_lo above every other candidate's q_hi (by 1e-4 relative, against
+// the two roundings of the quotient) needs neither rays nor intersection arithmetic under the reference's flat
+// shading (Kernels.cuh:95-99 uses the winner's vertices only, `hitpoint` is unused): every sample's radiance is A's
+// colour.  Its samples keep their RNG draws and their additions, nothing else.  (Not with spheres, smooth normals or
+// the nearest-hit rule, which need t, u, v.)
 template <bool FORMS = false, bool SURE = false>
 __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0, V3 e1, V3 e2, float* forms = nullptr,
-                                                     bool* sure_hit = nullptr) {
+                                                     bool* sure_hit = nullptr, float* q = nullptr) {
   // rounding allowance relative to the magnitude sums (DESIGN.md 4.1 "Rounding budget": <= ~20 half-ulps are
   // needed, 67 / 84 are charged).  RT_BIN_SLACK_SCALE exists for the teeth test of the adversarial campaign only
   // (tools/stress_boundaries.py against a build with the allowance scaled down must FIND mismatches).
@@ -404,6 +411,7 @@ __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0,
   float detc = 0.0f, det_rad = 0.0f, Uc = 0.0f, U_rad = 0.0f, Vc = 0.0f, V_rad = 0.0f;
   float DR = 0.0f, UR = 0.0f, VR = 0.0f;                            // FORMS: radii for a known origin
   float tmag = 0.0f;                                                // SURE: >= |dot(e2, (o - v0) x e1)|
+  float Ntc = 0.0f, Nt_rad = 0.0f;                                  // SURE: Nt = -(o - v0).N at the lens centre, radius over the lens
   float Nv[3] = {0.0f, 0.0f, 0.0f}, Gu[3] = {0.0f, 0.0f, 0.0f}, Gv[3] = {0.0f, 0.0f, 0.0f};
   float Eu[3] = {0.0f, 0.0f, 0.0f}, Ev[3] = {0.0f, 0.0f, 0.0f}, qd[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -428,7 +436,11 @@ __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0,
     U_rad += a[i] * (__builtin_fabsf(Gxe2) + rxe2) + r[i] * __builtin_fabsf(e2xt) + c * (T[i] * Wxe2 + a[i] * Gabs);
     Vc += wc[i] * txe1;
     V_rad += a[i] * __builtin_fabsf(e1xG) + r[i] * (__builtin_fabsf(txe1) + axe1) + c * (W[i] * Txe1 + a[i] * Gabs);
-    if constexpr (SURE) tmag += E2[i] * Txe1;
+    if constexpr (SURE) {
+      tmag += E2[i] * Txe1;
+      Ntc -= tvc[i] * N_i;
+      Nt_rad += a[i] * __builtin_fabsf(N_i);
+    }
     if constexpr (FORMS) {
       // a_r: what is left of |do_i| once the sample's own origin is used -- the roundings of o = pos + off
       // and of o - v0 (the aperture part A of orad is the known do itself)
@@ -477,6 +489,11 @@ __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0,
     const float det_lo = detc - det_rad;
     *sure_hit = (det_lo > (RT_EPS * 1.0001f) * f.lmax) && (U_lo >= 1e-4f * det_hi) && (V_lo >= 1e-4f * det_hi) &&
                 ((U_hi + V_hi) <= 0.9999f * det_lo) && (tmag * f.lmax < 1e37f * det_lo);
+    const float nt_rad = (Nt_rad + c * tmag) * RT_SLKM(1e-5f);
+    const float nt_lo = Ntc - nt_rad, nt_hi = Ntc + nt_rad;
+    const float inv_lo = __builtin_amdgcn_rcpf(det_lo), inv_hi = __builtin_amdgcn_rcpf(det_hi);   // (1 ulp: far inside the 1e-4 margin of the comparison)
+    q[0] = (nt_lo >= 0.0f) ? nt_lo * inv_hi : nt_lo * inv_lo;
+    q[1] = (det_lo > 0.0f) ? ((nt_hi >= 0.0f) ? nt_hi * inv_lo : nt_hi * inv_hi) : __builtin_inff();
   }
   const bool all_culled = det_hi < RT_EPS * f.lmin;
   const bool pos = det_hi > 0.0f;
@@ -666,10 +683,13 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   TileFamily fam;
   bool list_complete = false;       // the list in LDS covers the whole scene (classification done once)
   uint32_t list_count = 0;
-  // ONEPASS: the tile's list is exactly one triangle that every ray of the family certainly hits (wave-uniform):
-  // the sample loop then skips the intersection tests -- the winner is known (tile_misses_triangle<.., SURE>)
+  // ONEPASS: one triangle that every ray of the tile's family certainly hits is certainly the farthest hit of every ray
+  // (wave-uniform): the sample loop then needs neither rays nor tests (tile_misses_triangle<.., SURE>)
   bool sure_hit_tile = false;
-  uint32_t sure_kept = 0;
+  uint32_t sure_winner = 0;         // triangle index of the certain winner
+  bool lane_keep = false, lane_sure = false;      // this lane's verdicts of a one-step classification (lane = triangle)
+  float lane_q[2] = {0.0f, 0.0f};
+  uint32_t lane_tri = 0, class_steps = 0;
   const bool sure_ok = BIN && ONEPASS && (p.flags & (TRACE_NEAREST_HIT | TRACE_NO_SURE_HIT)) == 0u && p.n_spheres == 0u && p.tri_n == nullptr;
   // Block-level pre-cull (scenes larger than the per-wave list): the 256 threads classify every
   // triangle ONCE against the union of the block's four tile families and keep the survivors'
@@ -783,9 +803,9 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
           if (pretest) keep = valid && !tile_misses_triangle<true>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z}, forms);
           else keep = valid && !tile_misses_triangle(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z});
         } else if constexpr (ONEPASS) {
-          bool sure = false;
-          keep = valid && !tile_misses_triangle<false, true>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z}, nullptr, &sure);
-          sure_kept += static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(keep && sure)));
+          keep = valid && !tile_misses_triangle<false, true>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z}, nullptr,
+                                                             &lane_sure, lane_q);
+          lane_keep = keep; lane_tri = tri; class_steps += 1u;
         } else {
           keep = valid && !tile_misses_triangle(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z});
         }
@@ -834,8 +854,9 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
     if (p.flags & TRACE_LISTS_LOAD) {
       // wave-uniform by construction; readfirstlane tells the compiler (scalar loop control below)
       const uint32_t word = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(saved[0])));
-      const uint32_t count = word & 0x7FFFFFFFu;                     // bit 31: the stored list is ONE certainly-hit triangle
+      const uint32_t count = word & 0x3FFu;                          // bit 31: the tile has a certain winner, bits 10..19: its triangle
       sure_hit_tile = sure_ok && (word >> 31) != 0u;
+      sure_winner = (word >> 10) & 0x3FFu;
       for (uint32_t base = 0; base < count; base += 64u) {
         const uint32_t e = base + lane;
         if (e < count) {
@@ -851,10 +872,27 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
       list_count = count;
     } else {
       (void)classify(0u, std::false_type{});
-      const bool sure_one = list_count == 1u && sure_kept == 1u;       // (independent of the launch's flags: stored as such)
-      sure_hit_tile = sure_ok && sure_one;
+      // Certain winner (scenes classified in one step, lane = triangle): the certainly-hit candidate with the largest
+      // lower bound of q, if every other candidate's upper bound stays below it.
+      bool sure_one = false;
+      if (class_steps == 1u && fam.usable) {
+        const float NEG = -__builtin_inff();
+        const bool cand = lane_keep && lane_sure;
+        const float Q = uniform(wave_max(cand ? lane_q[0] : NEG));
+        const unsigned long long best = __builtin_amdgcn_ballot_w64(cand && lane_q[0] == Q);
+        if (best != 0ull) {
+          const uint32_t A = static_cast<uint32_t>(__builtin_ctzll(best));
+          const bool other = lane_keep && lane != A;
+          const float qhi = (lane_q[1] == lane_q[1]) ? lane_q[1] : __builtin_inff();     // a NaN bound is no bound (fmax would drop it)
+          const float R = uniform(wave_max(other ? qhi : NEG));
+          const bool alone = __builtin_amdgcn_ballot_w64(other) == 0ull;
+          sure_one = alone || (R < Q - 1e-4f * (__builtin_fabsf(R) + __builtin_fabsf(Q)));
+          sure_winner = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(lane_tri), static_cast<int>(A)));
+        }
+      }
+      sure_hit_tile = sure_ok && sure_one;                             // (sure_one is independent of the launch's flags: stored as such)
       if (p.flags & TRACE_LISTS_STORE) {
-        if (lane == 0u) saved[0] = list_count | (sure_one ? 0x80000000u : 0u);
+        if (lane == 0u) saved[0] = list_count | (sure_winner << 10) | (sure_one ? 0x80000000u : 0u);
         for (uint32_t e = lane; e < list_count; e += 64u) saved[1u + e] = static_cast<uint32_t>(cI[e]);
       }
     }
@@ -872,7 +910,11 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   }
   tl_mark(1);                                                      // family + classification done
   float4 sure_col = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  if constexpr (BIN && ONEPASS) { if (sure_hit_tile) sure_col = p.tri_color[cI[0]]; }
+  if constexpr (BIN && ONEPASS) { if (sure_hit_tile) sure_col = p.tri_color[sure_winner]; }
+  if constexpr (STATS && BIN && ONEPASS) {                         // tiles by list length: 0, 1, 1 and certainly hit, 2, more
+    if (lane == 0u && p.stats != nullptr)
+      atomicAdd(p.stats + (list_count == 0u ? 11 : list_count == 1u ? (sure_hit_tile ? 13 : 12) : list_count == 2u ? 14 : 15), 1ull);
+  }
   const uint32_t iters = FUSE ? p.iters : 1u;
   float rx = 0.0f, ry = 0.0f, rz = 0.0f, rw = 0.0f;                // FUSE: the pixel's RenderBuffer value so far
   uint32_t cnt_first = 0u;

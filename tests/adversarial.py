@@ -19,7 +19,9 @@ tile-corner pixels, lens samples on the rim of the aperture or at its centre -- 
             of u, v is dominated by rounding (error ~ 10 ulp * distance / size);
   cover     contains the whole footprint of a tile's family (the four corner pixels' rays, lens rim included) with a
             margin of 0, 1e-6, 1e-4, 1e-2 or 1 of its size: the "certainly hit" verdict (tiles whose one candidate
-            needs no intersection test) decides just inside / just outside its own boundary;
+            needs no intersection test) decides just inside / just outside its own boundary; half of them are
+            STACKED on the previous one at a distance larger by 0, 1e-7 ... 1e-2 relative (which of two certain hits is
+            the farther one, Kernels.cuh:84, is decided by bounds as well);
   filler    plain random triangles around all of that (candidate lists of realistic length),
 
 at coordinate scales 1e-3 ... 1e4 and apertures from 0 to many times the scene.  The camera math below is a
@@ -92,6 +94,7 @@ def adversarial_triangles(rng, cam, W, H, n, scale):
     tris = np.zeros((n, 3, 3), np.float64)
     kinds = rng.choice(7, n, p=[0.18, 0.18, 0.09, 0.1, 0.1, 0.23, 0.12])
     jitter = rng.choice([0, 1, 2, 4, 16, 64], n, p=[0.15, 0.2, 0.2, 0.2, 0.15, 0.1])
+    last_cover = None
     for i in range(n):
         o, d, focal, dc = _pick_ray(rng, cam, W, H)
         t = float(rng.choice([-1.0, 1.0, 1.0, 1.0]) * scale * 10.0 ** rng.uniform(-1.0, 1.0))
@@ -138,6 +141,10 @@ def adversarial_triangles(rng, cam, W, H, n, scale):
             tris[i] = (P, v1, v2) if rng.integers(0, 2) else (v1, v2, P)
         elif k == 6:                                                  # covers the tile family's footprint at distance t, by a margin
             tx, ty = rng.integers(0, (W + 7) // 8), rng.integers(0, (H + 7) // 8)
+            if last_cover is not None and rng.integers(0, 2):          # stacked behind / in front of the previous cover
+                tx, ty, t0 = last_cover
+                t = t0 * (1.0 + float(rng.choice([0.0, 1e-7, 1e-6, 1e-5, 1e-4, 1e-3, 1e-2])) * rng.choice([-1.0, 1.0]))
+            last_cover = (tx, ty, t)
             pts = []
             for cxp, cyp in ((0, 0), (7, 0), (0, 7), (7, 7)):
                 for lens in ((1.0, 0.0), (-1.0, 0.0), (0.0, 1.0), (0.0, -1.0)):
