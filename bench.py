@@ -353,6 +353,12 @@ def main():
             waves = ((cfg["width"] + 7) // 8) * ((cfg["height"] + 7) // 8)
             valu["binning"] = {"candidates_per_tile": round(sb["bin_candidates"] / max(sb["bin_rounds"], 1), 2),
                                "of_triangles": n_tris, "classification_rounds_per_tile": round(sb["bin_rounds"] / waves, 3)}
+            tl = sb.get("tiles_by_list", {})
+            if sum(tl.values()):
+                valu["binning"]["tiles"] = {k: round(v / sum(tl.values()), 4) for k, v in tl.items()}
+                valu["binning"]["tiles_note"] = ("share of the 8x8 tiles with a CERTAIN winner (one triangle every ray of the tile's family certainly hits "
+                                                 "and that is certainly the farthest hit: their samples keep only the RNG draws and the additions), and of "
+                                                 "the others by the length of their candidate list")
             out["valu"] = valu
         if n_parts == 1 and args.cpu_rows != 0:
             rows = args.cpu_rows if args.cpu_rows > 0 else min(cfg["height"], {"C2": 512, "C3": 1080, "C4": 8, "C5": 2}[args.config])

@@ -184,7 +184,8 @@ int  rt_tracer_kernel_time(rt_tracer* t, double* total_ms, uint64_t* launches, i
  *             rounds; out[9] classification rounds (one per wave when its list fits in LDS).
  *   out[10]   large scenes: candidate tests of a sample batch skipped by the per-sample forms; small scenes: sample
  *             batches of tiles that skipped their tests because the one candidate is certainly hit;
- *   out[11..15] small scenes: tiles whose candidate list holds 0 / 1 / 1 certainly hit / 2 / more triangles. */
+ *   out[11..15] small scenes: tiles without candidates / with 1 / with a certain winner (any list length) / with 2 /
+ *             with more candidates. */
 int  rt_tracer_trace_stats(rt_tracer* t, uint32_t samples, uint64_t out[16]);
 /* Copy one of the tracer's device buffers to host memory / to another device pointer. */
 int  rt_tracer_read_buffer(rt_tracer* t, int which, void* dst, size_t bytes);

@@ -351,7 +351,7 @@ class RayTracer:
         return {"exit_det": v[0], "exit_u": v[1], "exit_v": v[2], "exit_hit": v[3],
                 "skip_a": v[4], "skip_b": v[5], "skip_c": v[6], "reach_d": v[7],
                 "bin_candidates": v[8], "bin_rounds": v[9], "pretest_skips": v[10],
-                "tiles_by_list": {"0": v[11], "1": v[12], "1_sure": v[13], "2": v[14], "more": v[15]}}
+                "tiles_by_list": {"0": v[11], "1": v[12], "sure": v[13], "2": v[14], "more": v[15]}}
 
     def KernelTime(self, reset=True):
         ms, n = C.c_double(), C.c_uint64()

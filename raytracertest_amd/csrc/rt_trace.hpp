@@ -911,9 +911,9 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   tl_mark(1);                                                      // family + classification done
   float4 sure_col = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   if constexpr (BIN && ONEPASS) { if (sure_hit_tile) sure_col = p.tri_color[sure_winner]; }
-  if constexpr (STATS && BIN && ONEPASS) {                         // tiles by list length: 0, 1, 1 and certainly hit, 2, more
+  if constexpr (STATS && BIN && ONEPASS) {                         // tiles with a certain winner; the others by list length: 0, 1, 2, more
     if (lane == 0u && p.stats != nullptr)
-      atomicAdd(p.stats + (list_count == 0u ? 11 : list_count == 1u ? (sure_hit_tile ? 13 : 12) : list_count == 2u ? 14 : 15), 1ull);
+      atomicAdd(p.stats + (sure_hit_tile ? 13 : list_count == 0u ? 11 : list_count == 1u ? 12 : list_count == 2u ? 14 : 15), 1ull);
   }
   const uint32_t iters = FUSE ? p.iters : 1u;
   float rx = 0.0f, ry = 0.0f, rz = 0.0f, rw = 0.0f;                // FUSE: the pixel's RenderBuffer value so far
