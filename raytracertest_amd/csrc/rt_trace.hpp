@@ -1097,6 +1097,11 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   }
   }                                                                // iterations
   tl_mark(3);                                                      // all samples done
+  // The epilogue forms its addresses afresh from the pixel index: kept live from the prologue's RNG loads they are
+  // four 64-bit values that no longer fit the 96-VGPR budget (spilled: 130 MB of scratch traffic per C3 launch).
+  uint32_t pix_lo = static_cast<uint32_t>(pix);                     // (a band has < 2^32 pixels)
+  asm volatile("" : "+v"(pix_lo));
+  const size_t pix_e = pix_lo;
   if (inside) {
     // Accumulators are read here, not prefetched at kernel start: five registers held across
     // the whole kernel cost more (spills at the 96-VGPR budget of 5 waves/SIMD) than the exposed
@@ -1105,33 +1110,33 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
     uint32_t cnt_in = 0u;
     if constexpr (!FUSE) {
       if (!(p.flags & TRACE_ZERO_ACC)) {                            // wave-uniform
-        acc_in = p.render[pix];
-        cnt_in = p.counts[pix];
+        acc_in = p.render[pix_e];
+        cnt_in = p.counts[pix_e];
       }
     }
     const uint32_t cnt = FUSE ? cnt_first + iters * p.samples : cnt_in + p.samples;   // :140
-    p.counts[pix] = cnt;
+    p.counts[pix_e] = cnt;
     float4 acc = acc_in;
     if constexpr (FUSE) {
       acc = make_float4(rx, ry, rz, rw);
     } else {
       acc.x += ax; acc.y += ay; acc.z += az;                        // :141-143, alpha untouched (:144)
     }
-    p.render[pix] = acc;
+    p.render[pix_e] = acc;
     if (p.flags & TRACE_EMIT_IMAGE) {                               // fused rt::ConverterKernel, :164-168
       const float c = static_cast<float>(cnt);
       const uint32_t bgra = rtd::pack_color(255.0f * (acc.x / c), 255.0f * (acc.y / c), 255.0f * (acc.z / c));
-      p.image[pix] = bgra;
+      p.image[pix_e] = bgra;
       // update hand-off: the same value straight into the caller-visible pinned host image (posted
       // PCIe writes, one 256-byte row segment per wave store) -- no device-to-host copy afterwards
-      if (p.image_host != nullptr) p.image_host[pix] = bgra;
+      if (p.image_host != nullptr) p.image_host[pix_e] = bgra;
     }
-    p.rng[0 * static_cast<size_t>(p.npix) + pix] = rng.d;           // :146
-    p.rng[1 * static_cast<size_t>(p.npix) + pix] = rng.v0;
-    p.rng[2 * static_cast<size_t>(p.npix) + pix] = rng.v1;
-    p.rng[3 * static_cast<size_t>(p.npix) + pix] = rng.v2;
-    p.rng[4 * static_cast<size_t>(p.npix) + pix] = rng.v3;
-    p.rng[5 * static_cast<size_t>(p.npix) + pix] = rng.v4;
+    p.rng[0 * static_cast<size_t>(p.npix) + pix_e] = rng.d;           // :146
+    p.rng[1 * static_cast<size_t>(p.npix) + pix_e] = rng.v0;
+    p.rng[2 * static_cast<size_t>(p.npix) + pix_e] = rng.v1;
+    p.rng[3 * static_cast<size_t>(p.npix) + pix_e] = rng.v2;
+    p.rng[4 * static_cast<size_t>(p.npix) + pix_e] = rng.v3;
+    p.rng[5 * static_cast<size_t>(p.npix) + pix_e] = rng.v4;
   }
   tl_mark(4);                                                      // stores issued
   if constexpr (STATS) {
