@@ -274,6 +274,7 @@ __device__ __forceinline__ void test_triangle(const float4 A0, const float4 A1, 
 // ------------------------------------------------------------------------------------
 struct TileFamily {
   float oc[3], orad[3];   // lens origin box (wave-uniform)
+  float A;                // radius of the lens DISK inside that box: the aperture part of orad[0], orad[1]
   float fc[3], frad[3];   // focal point box over the tile's pixels (wave-uniform)
   float lmin, lmax;       // bounds of |F - o| over the family
   bool usable;            // false: bounds not finite -> keep every triangle
@@ -328,6 +329,7 @@ __device__ __forceinline__ TileFamily make_family(const TraceParams& p, const Fo
   f.orad[0] = A + RT_SLK(1e-6f) * __builtin_fabsf(f.oc[0]);
   f.orad[1] = A + RT_SLK(1e-6f) * __builtin_fabsf(f.oc[1]);
   f.orad[2] = RT_SLK(1e-6f) * __builtin_fabsf(f.oc[2]);
+  f.A = A;
   float lmin2 = 0.0f, lmax2 = 0.0f;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -414,6 +416,7 @@ __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0,
   float Ntc = 0.0f, Nt_rad = 0.0f;                                  // SURE: Nt = -(o - v0).N at the lens centre, radius over the lens
   float Nv[3] = {0.0f, 0.0f, 0.0f}, Gu[3] = {0.0f, 0.0f, 0.0f}, Gv[3] = {0.0f, 0.0f, 0.0f};
   float Eu[3] = {0.0f, 0.0f, 0.0f}, Ev[3] = {0.0f, 0.0f, 0.0f}, qd[3] = {0.0f, 0.0f, 0.0f};
+  float cn[3], cu[3], cv[3];                                        // |coefficient| of do_i in det', U', V' (lens terms)
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int j = (i + 1) % 3, k = (i + 2) % 3;                     // cross(x, y)_i = x_j*y_k - y_j*x_k
@@ -436,6 +439,7 @@ __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0,
     U_rad += a[i] * (__builtin_fabsf(Gxe2) + rxe2) + r[i] * __builtin_fabsf(e2xt) + c * (T[i] * Wxe2 + a[i] * Gabs);
     Vc += wc[i] * txe1;
     V_rad += a[i] * __builtin_fabsf(e1xG) + r[i] * (__builtin_fabsf(txe1) + axe1) + c * (W[i] * Txe1 + a[i] * Gabs);
+    cn[i] = __builtin_fabsf(N_i); cu[i] = __builtin_fabsf(Gxe2) + rxe2; cv[i] = __builtin_fabsf(e1xG);
     if constexpr (SURE) {
       tmag += E2[i] * Txe1;
       Ntc -= tvc[i] * N_i;
@@ -479,6 +483,16 @@ __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0,
       forms[6] += qd[i] * __builtin_fabsf(g3) * RT_SLKM(1e-5f);
     }
   }
+  // The lens is a DISK of radius A, the sums above took it as the box [-A, A]^2: a term do.g (do_z = 0) was charged
+  // A (|g_x| + |g_y|) where A |g_xy| suffices, and max + 0.4143 min >= sqrt(max^2 + min^2).  Take the difference back,
+  // a little less than all of it (0.585 < 1 - 0.41422).  (The rounding parts of a[], the bilinear do x dF term of V' and
+  // the magnitude bounds W, T keep the box.)
+  const float disk = 0.585f * f.A;
+  const float dn = disk * fminf(cn[0], cn[1]);
+  det_rad -= dn;
+  U_rad -= disk * fminf(cu[0], cu[1]);
+  V_rad -= disk * fminf(cv[0], cv[1]);
+  if constexpr (SURE) Nt_rad -= dn;
   det_rad = det_rad * RT_SLKM(1e-5f);
   U_rad = U_rad * RT_SLKM(1e-5f);
   V_rad = V_rad * RT_SLKM(1e-5f);
