@@ -283,6 +283,9 @@ int rt_dbg_valu_peak(int device, double* lane_fma_per_s, double* clock_ghz);
  * [2^-96, 2^96] against the generic correctly rounded expansions.  out = {values checked, sqrt mismatches,
  * reciprocal mismatches, bit pattern of a mismatching operand or 0}. */
 int rt_dbg_check_midrange(int device, uint64_t out[4]);
+/* The stored tile candidate lists of a small-scene tracer (after a launch that stored them): per 8x8 wave tile, in grid
+ * order (4 per 32x8 block), *words_per_tile words: count | winner << 10 | certain-winner << 31, then the triangle indices. */
+int rt_dbg_read_tile_lists(rt_tracer* t, uint32_t* dst, size_t capacity_words, uint32_t* words_per_tile);
 /* states n*6 {d,v0..v4} advanced in place, out n*m uniforms in (0,1] */
 int rt_dbg_uniform(int device, uint32_t n, uint32_t m, uint32_t* states, float* out);
 /* thin-lens rays of the tracer's current camera for n (x, y) pixels with given RNG states */

@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "rt_dbg_rng_init_host",
     "rt_tracer_create_multi", "rt_group_unique_id", "rt_tracer_join_group", "rt_tracer_leave_group",
     "rt_tracer_gather_time", "rt_tracer_band_count", "rt_tracer_band_info",
-    "rt_tracer_join_group_bands", "rt_balance_rows", "rt_tracer_rebalance", "rt_tracer_set_band",
+    "rt_tracer_join_group_bands", "rt_balance_rows", "rt_tracer_rebalance", "rt_tracer_set_band", "rt_dbg_read_tile_lists",
 ]
 
 
@@ -179,6 +179,7 @@ def load_library():
         L.rt_balance_rows.argtypes = [C.c_uint32, u32p, C.POINTER(C.c_double), C.c_uint32, u32p]
         L.rt_tracer_rebalance.argtypes = [vp]
         L.rt_tracer_set_band.argtypes = [vp, C.c_uint32, C.c_uint32]
+        L.rt_dbg_read_tile_lists.argtypes = [vp, u32p, C.c_size_t, u32p]
         _lib = L
         return _lib
 
@@ -443,6 +444,16 @@ class RayTracer:
 
     def LastError(self):
         return self._lib.rt_tracer_last_error(self._h).decode()
+
+    def DebugTileLists(self):
+        """(tiles_y, tiles_x) arrays (count, winner triangle, certain-winner flag) of the stored tile lists."""
+        bx, by = (self.width + 31) // 32, (self.rows + 7) // 8
+        wpt = np.zeros(1, np.uint32)
+        buf = np.zeros(bx * (by + 1) * 4 * 1025, np.uint32)
+        self._check(self._lib.rt_dbg_read_tile_lists(self._h, _u32p(buf), buf.size, _u32p(wpt)))
+        w = int(wpt[0])
+        words = buf[:bx * by * 4 * w].reshape(by, bx * 4, w)[:, :, 0]
+        return (words & 0x3FF).astype(np.int32), ((words >> 10) & 0x3FF).astype(np.int32), (words >> 31).astype(bool)
 
     def DebugGetRay(self, pixels, states):
         pix = np.ascontiguousarray(pixels, np.uint32).reshape(-1, 2)

@@ -1496,6 +1496,22 @@ extern "C" int rt_dbg_trace_timeline(rt_tracer* t, uint32_t samples, unsigned lo
 }
 #endif
 
+// the stored tile candidate lists of a small-scene tracer, as the last storing launch wrote them: per wave tile
+// (grid order, 4 per 32x8 block) 1 + bin_list words; word 0 = count | winner << 10 | certain << 31.  Measurement aid.
+int rt_dbg_read_tile_lists(rt_tracer* t, uint32_t* dst, size_t capacity_words, uint32_t* words_per_tile) {
+  if (!t || t->mg || !dst) return RT_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(t->api_mu);
+  return guarded(t, [&] {
+    t->cancel_and_join();
+    t->use_device();
+    HIP_CHECK(hipStreamSynchronize(t->main_stream()));
+    if (!t->d_tile_lists || !t->list_key_valid) throw HipFail{"no stored tile lists (small scenes store them on the second launch of a Trace)"};
+    const size_t n = t->tile_lists_words < capacity_words ? t->tile_lists_words : capacity_words;
+    HIP_CHECK(hipMemcpy(dst, t->d_tile_lists, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (words_per_tile) *words_per_tile = 1u + t->list_key.bin_list;
+  });
+}
+
 int rt_dbg_trace_occupancy(int device, int samples_in_flight, uint32_t lds_bytes) {
   if (require_device(device) != RT_OK) return -1;
   if (hipSetDevice(device) != hipSuccess) return -1;
