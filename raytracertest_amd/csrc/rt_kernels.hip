@@ -284,14 +284,6 @@ hipError_t launch_macro_bin(const TraceParams& p, bool fma, hipStream_t st) {
   return hipGetLastError();
 }
 
-hipError_t launch_region_verdicts(const TraceParams& p, bool fma, hipStream_t st) {
-  if (p.regions == nullptr || p.n_tris == 0u || p.n_tris > 64u || p.rows == 0u || p.W == 0u) return hipSuccess;
-  const dim3 grid(cdiv(p.W, p.region_w), cdiv(p.rows, p.region_h));
-  if (fma) hipLaunchKernelGGL(region_verdict_kernel<true>, grid, dim3(64), 0, st, p);
-  else hipLaunchKernelGGL(region_verdict_kernel<false>, grid, dim3(64), 0, st, p);
-  return hipGetLastError();
-}
-
 // every float in [2^-96, 2^96]: sqrt_midrange / rcp_midrange against the generic expansions
 __global__ __launch_bounds__(256) void dbg_check_midrange_kernel(unsigned long long* __restrict__ out) {
   const uint32_t first = 0x0F800000u, last = 0x6F800000u;

@@ -42,11 +42,6 @@ struct TraceParams {
   // followed by macro_cap ascending triangle indices.  null = no macro level.
   uint32_t* macro_lists;
   uint32_t  macro_cap, macro_w, macro_h, macro_nx;
-  // Region verdicts (small scenes): written by region_verdict_kernel ahead of a classifying trace launch, one word per
-  // region of region_w x region_h pixels (whole trace blocks): winner triangle | 1 << 31 when the region's ray family has
-  // a certain winner, else 0.  null = no region level.
-  uint32_t* regions;
-  uint32_t  region_w, region_h, region_nx;
   uint32_t* tile_lists; // per wave tile: count + bin_list triangle indices (TRACE_LISTS_*), or null
   uint32_t  flags;     // TRACE_*
 };
@@ -84,7 +79,6 @@ hipError_t launch_dbg_hit_triangle(bool fma, uint32_t n, const float* rays, cons
                                    int* hit, float* tuv, float* normal, float* point, hipStream_t st);
 bool trace_can_fuse(bool filter, bool bin);      // launches with TraceParams::iters > 1 are available
 hipError_t launch_macro_bin(const TraceParams& p, bool fma, hipStream_t st);
-hipError_t launch_region_verdicts(const TraceParams& p, bool fma, hipStream_t st);
 hipError_t launch_dbg_check_midrange(unsigned long long* out, hipStream_t st);
 hipError_t launch_dbg_valu_peak(uint32_t blocks, int iters, float* out, unsigned long long* clk, hipStream_t st);
 hipError_t launch_dbg_sincos(uint32_t n, const float* x, float* s, float* c, hipStream_t st);

@@ -515,81 +515,6 @@ __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0,
   return all_culled || out;
 }
 
-// The verdicts of a one-step classification (lane = triangle: kept, certainly hit, bounds q[0] <= q <= q[1] of Nt/det')
-// -> the family's certain winner, if it has one: the certainly-hit candidate with the largest lower bound of q, provided
-// every other candidate's upper bound stays below it by 1e-4 relative.  Equal bounds (duplicate triangles) are no
-// certain winner; among equal lower bounds the lowest lane = the first-scanned triangle is examined (Kernels.cuh:84).
-__device__ __forceinline__ bool certain_winner(bool keep, bool sure, const float (&q)[2], uint32_t tri, uint32_t lane, uint32_t& winner) {
-  const float NEG = -__builtin_inff();
-  const bool cand = keep && sure;
-  const float Q = uniform(wave_max(cand ? q[0] : NEG));
-  const unsigned long long best = __builtin_amdgcn_ballot_w64(cand && q[0] == Q);
-  if (best == 0ull) return false;
-  const uint32_t A = static_cast<uint32_t>(__builtin_ctzll(best));
-  const bool other = keep && lane != A;
-  const float qhi = (q[1] == q[1]) ? q[1] : __builtin_inff();       // a NaN bound is no bound (fmax would drop it)
-  const float R = uniform(wave_max(other ? qhi : NEG));
-  const bool alone = __builtin_amdgcn_ballot_w64(other) == 0ull;
-  winner = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(tri), static_cast<int>(A)));
-  return alone || (R < Q - 1e-4f * (__builtin_fabsf(R) + __builtin_fabsf(Q)));
-}
-
-// pixel -> camera-space image-plane coordinates, ThinLensCamera.cuh:116-119 (the same operations pinhole() performs)
-__device__ __forceinline__ void pixel_cs(const TraceParams& p, uint32_t px, uint32_t py, float& cx, float& cy) {
-  const float nx = (static_cast<float>(px) + 0.5f) / static_cast<float>(p.W);
-  const float ny = (static_cast<float>(py) + 0.5f) / static_cast<float>(p.H);
-  cx = ((2.0f * nx - 1.0f) * p.half_height) * p.aspect;
-  cy = (1.0f - 2.0f * ny) * p.half_height;
-}
-
-// ------------------------------------------------------------------------------------
-// Region level of the certain-winner verdict (small scenes, one wave per region of region_w x region_h pixels, run on
-// the stream ahead of a trace launch that classifies).  Tiles with a certain winner come in large patches (C3: 39 % of
-// the tiles lie in 32 x 32-pixel regions that are certain with one winner); a tile of such a region needs no ray family
-// and no classification of its own -- 58 % of what a certain-winner tile costs.  The region's family is not taken from
-// its 1024 pixels but from its FOUR CORNER pixels' focal points, computed exactly as the trace kernel computes them,
-// widened by what the focal point can deviate from the bilinear interpolant of the corners: F = pos + focal d,
-// d = M q / |M q| with q = (cx, cy, -1), M orthonormal; along an axis direction h the second derivative of q/|q| is
-// ((3c^2 - 1) q/|q| - 2 c h) / |q|^2 with c = (q.h)/|q|, of norm <= 4 / |q|^2 <= 4, so over a rectangle of sides a x b in
-// (cx, cy) each component of d stays within (a^2 + b^2)/8 * 4 of the interpolant, whose extremes are at the corners.
-// cx, cy are monotone in the pixel index (rounded operations are monotone), so the corner pixels bound the rectangle.
-// Everything after the bounds -- make_family, the SURE classification, the winner rule -- is the tiles' own code.
-// ------------------------------------------------------------------------------------
-template <bool FMA>
-__global__ __launch_bounds__(64) void region_verdict_kernel(TraceParams p) {
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t x0 = blockIdx.x * p.region_w, y0 = blockIdx.y * p.region_h;
-  const uint32_t x1 = (x0 + p.region_w < p.W) ? x0 + p.region_w : p.W;            // exclusive
-  const uint32_t y1 = (y0 + p.region_h < p.rows) ? y0 + p.region_h : p.rows;
-  const uint32_t px = (lane & 1u) ? x1 - 1u : x0, ly = (lane & 2u) ? y1 - 1u : y0;   // this lane's corner
-  V3 po, pd;
-  pinhole<FMA>(p, px, p.row0 + ly, po, pd);
-  const V3 f = focal_point<FMA>(p, pd);
-  FocalBounds b = focal_bounds(f, true);
-  float ax0, ay0, ax1, ay1;
-  pixel_cs(p, x0, p.row0 + y0, ax0, ay0);
-  pixel_cs(p, x1 - 1u, p.row0 + y1 - 1u, ax1, ay1);
-  const float a = ax1 - ax0, bb = ay1 - ay0;
-  const float dev = __builtin_fabsf(p.focal) * (0.5f * (a * a + bb * bb) * 1.0001f + 1e-6f);   // |F - interpolant|, per component
-  b.ok = b.ok && (dev <= FLT_MAX);                                   // (NaN / inf camera: no verdict)
-#pragma unroll
-  for (int i = 0; i < 3; ++i) { b.lo[i] -= dev; b.hi[i] += dev; }
-  const TileFamily fam = make_family(p, b);
-  uint32_t verdict = 0u;
-  if (fam.usable && p.n_tris <= 64u) {
-    const bool valid = lane < p.n_tris;
-    const uint32_t ti = valid ? lane : 0u;
-    const float4 A0 = p.tri_a[2u * ti], A1 = p.tri_a[2u * ti + 1u];
-    const float bz = p.tri_b[ti];
-    bool sure = false;
-    float q[2] = {0.0f, 0.0f};
-    const bool keep = valid && !tile_misses_triangle<false, true>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z}, nullptr, &sure, q);
-    uint32_t winner = 0u;
-    if (certain_winner(keep, sure, q, ti, lane, winner)) verdict = 0x80000000u | winner;
-  }
-  if (lane == 0u) p.regions[static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x] = verdict;
-}
-
 // ------------------------------------------------------------------------------------
 // Macro level of the triangle classification (scenes larger than the per-wave list).
 // One block per macro tile of macro_w x macro_h pixels (whole trace blocks): the focal points of
@@ -728,24 +653,9 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   rng.v4 = p.rng[5 * static_cast<size_t>(p.npix) + pix];
 
 
-  // Small scenes: the region this block lies in may already have a certain winner (region_verdict_kernel): then the
-  // tile needs no pinhole ray, no family and no classification.  (The host passes p.regions only to launches whose
-  // flags allow a certain winner and that classify at all.)
-  bool region_sure = false;
-  uint32_t region_winner = 0u;
-  if constexpr (BIN && ONEPASS) {
-    if (p.regions != nullptr) {
-      const uint32_t rv = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(
-          p.regions[static_cast<size_t>(blockIdx.y * 8u / p.region_h) * p.region_nx + blockIdx.x * 32u / p.region_w])));
-      region_sure = (rv >> 31) != 0u;
-      region_winner = rv & 0x3FFu;
-    }
-  }
-  V3 po = {0.0f, 0.0f, 0.0f}, pd = {0.0f, 0.0f, 0.0f}, focal = {0.0f, 0.0f, 0.0f};
-  if (!region_sure) {                                               // wave-uniform
-    pinhole<FMA>(p, cxp, p.row0 + cyp, po, pd);
-    focal = focal_point<FMA>(p, pd);
-  }
+  V3 po, pd;
+  pinhole<FMA>(p, cxp, p.row0 + cyp, po, pd);
+  const V3 focal = focal_point<FMA>(p, pd);
 
   const uint32_t n = p.n_tris;
   // false: the reference's rule (keep the farthest t, negative t accepted, Kernels.cuh:73,84);
@@ -824,9 +734,9 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
     wb.ok = false; wb.any = false;
 #pragma unroll
     for (int i = 0; i < 3; ++i) { wb.lo[i] = 0.0f; wb.hi[i] = 0.0f; }
-    if (!lists_loaded && !region_sure) wb = focal_bounds(focal, inside);
+    if (!lists_loaded) wb = focal_bounds(focal, inside);
     tl_mark(9);
-    if (!lists_loaded && !region_sure) fam = make_family(p, wb);
+    if (!lists_loaded) fam = make_family(p, wb);
     else fam.usable = false;
     tl_mark(10);
     if constexpr (!ONEPASS) {
@@ -955,11 +865,7 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   if constexpr (BIN && ONEPASS) {
     const size_t slot = (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 4u + wave;
     uint32_t* const saved = p.tile_lists + slot * (1u + L);
-    if (region_sure) {                                             // nothing to classify: the region's winner is the tile's
-      sure_hit_tile = true;
-      sure_winner = region_winner;
-      if ((p.flags & TRACE_LISTS_STORE) && lane == 0u) saved[0] = (region_winner << 10) | 0x80000000u;   // count 0 + the verdict
-    } else if (p.flags & TRACE_LISTS_LOAD) {
+    if (p.flags & TRACE_LISTS_LOAD) {
       // wave-uniform by construction; readfirstlane tells the compiler (scalar loop control below)
       const uint32_t word = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(saved[0])));
       const uint32_t count = word & 0x3FFu;                          // bit 31: the tile has a certain winner, bits 10..19: its triangle
@@ -983,7 +889,21 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
       // Certain winner (scenes classified in one step, lane = triangle): the certainly-hit candidate with the largest
       // lower bound of q, if every other candidate's upper bound stays below it.
       bool sure_one = false;
-      if (class_steps == 1u && fam.usable) sure_one = certain_winner(lane_keep, lane_sure, lane_q, lane_tri, lane, sure_winner);
+      if (class_steps == 1u && fam.usable) {
+        const float NEG = -__builtin_inff();
+        const bool cand = lane_keep && lane_sure;
+        const float Q = uniform(wave_max(cand ? lane_q[0] : NEG));
+        const unsigned long long best = __builtin_amdgcn_ballot_w64(cand && lane_q[0] == Q);
+        if (best != 0ull) {
+          const uint32_t A = static_cast<uint32_t>(__builtin_ctzll(best));
+          const bool other = lane_keep && lane != A;
+          const float qhi = (lane_q[1] == lane_q[1]) ? lane_q[1] : __builtin_inff();     // a NaN bound is no bound (fmax would drop it)
+          const float R = uniform(wave_max(other ? qhi : NEG));
+          const bool alone = __builtin_amdgcn_ballot_w64(other) == 0ull;
+          sure_one = alone || (R < Q - 1e-4f * (__builtin_fabsf(R) + __builtin_fabsf(Q)));
+          sure_winner = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(lane_tri), static_cast<int>(A)));
+        }
+      }
       sure_hit_tile = sure_ok && sure_one;                             // (sure_one is independent of the launch's flags: stored as such)
       if (p.flags & TRACE_LISTS_STORE) {
         if (lane == 0u) saved[0] = list_count | (sure_winner << 10) | (sure_one ? 0x80000000u : 0u);

@@ -381,7 +381,6 @@ struct rt_tracer {
       attach_tile_lists(p, 0, list_flags);
       if (timed) HIP_CHECK(hipEventRecord(e.a, stream));
       attach_macro_lists(p, 0, stream);                                  // part of the launch: timed with it
-      attach_regions(p, 0, stream, list_flags);
       HIP_CHECK(rtk::launch_trace(p, fma, filter, bin, K, stream));
       if (timed) HIP_CHECK(hipEventRecord(e.b, stream));
     } else {
@@ -392,7 +391,6 @@ struct rt_tracer {
       for (int h = 0; h < 2; ++h) {
         attach_tile_lists(half[h], h, list_flags);
         attach_macro_lists(half[h], h, st[h]);
-        attach_regions(half[h], h, st[h], list_flags);
         HIP_CHECK(rtk::launch_trace(half[h], fma, filter, bin, K, st[h]));
       }
       if (timed) { HIP_CHECK(hipEventRecord(e.b, stream)); HIP_CHECK(hipEventRecord(e.c, stream_b)); }
@@ -580,34 +578,6 @@ struct rt_tracer {
     }
     p.macro_lists = d_macro_lists[half];
     HIP_CHECK(rtk::launch_macro_bin(p, fma, st));
-  }
-
-  // Region level of the certain-winner verdict (scenes classified in one step: <= 64 triangles): one word per region of
-  // 32 x 32 pixels, written by region_verdict_kernel on the stream ahead of every trace launch that classifies (the
-  // camera may have changed; 2 025 one-wave blocks at 1080p, timed with the launch).
-  uint32_t* d_regions[2] = {nullptr, nullptr};       // one per half of a split launch
-  size_t regions_words[2] = {0, 0};
-  bool regions = true;                // RT_MI355X_NO_REGIONS=1 turns the region level off
-  void attach_regions(rtk::TraceParams& p, int half, hipStream_t st, uint32_t list_flags) {
-    p.regions = nullptr;
-    if (!regions || !sure_hit || !bin || nearest_hit || p.n_spheres != 0u || p.tri_n != nullptr || p.n_tris == 0u || p.n_tris > 64u ||
-        p.n_tris > p.bin_list || p.stats != nullptr || (list_flags & rtk::TRACE_LISTS_LOAD) != 0u)
-      return;
-    p.region_w = 32u; p.region_h = 32u;
-    if (const char* rs = getenv("RT_MI355X_REGION")) {                  // tuning: "WxH", multiples of 32 x 8
-      unsigned w = 0, h = 0;
-      if (sscanf(rs, "%ux%u", &w, &h) == 2 && w >= 32u && h >= 8u && w % 32u == 0u && h % 8u == 0u) { p.region_w = w; p.region_h = h; }
-    }
-    p.region_nx = (p.W + p.region_w - 1u) / p.region_w;
-    const size_t words = static_cast<size_t>(p.region_nx) * ((p.rows + p.region_h - 1u) / p.region_h);
-    if (words > regions_words[half]) {
-      if (d_regions[half]) (void)hipFree(d_regions[half]);
-      d_regions[half] = nullptr; regions_words[half] = 0;
-      HIP_CHECK(hipMalloc(&d_regions[half], words * sizeof(uint32_t)));
-      regions_words[half] = words;
-    }
-    p.regions = d_regions[half];
-    HIP_CHECK(rtk::launch_region_verdicts(p, fma, st));
   }
 
   static constexpr int kWindow = 4;
@@ -863,7 +833,6 @@ int rt_tracer_create_ex(const uint32_t imageSize[2], const float cameraPosition[
   t->nearest_hit = (opt.flags & RT_FLAG_NEAREST_HIT) != 0;
   t->smooth_normals = (opt.flags & RT_FLAG_SMOOTH_NORMALS) != 0;
   { const char* np = getenv("RT_MI355X_NO_PRETEST"); t->pretest = !(np && np[0] == '1'); }
-  { const char* nr = getenv("RT_MI355X_NO_REGIONS"); t->regions = !(nr && nr[0] == '1'); }
   { const char* nh = getenv("RT_MI355X_NO_SUREHIT"); t->sure_hit = (opt.flags & RT_FLAG_NO_SURE_HIT) == 0 && !(nh && nh[0] == '1'); }
   { const char* ns = getenv("RT_MI355X_NO_SPLIT"); t->split_launches = !(ns && ns[0] == '1'); }
   if (const char* es = getenv("RT_MI355X_EVENT_STRIDE")) t->event_stride = static_cast<uint32_t>(strtoul(es, nullptr, 10));
@@ -931,7 +900,6 @@ void rt_tracer_destroy(rt_tracer* t) {                                   // RayT
   for (EventPair& e : t->free_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); (void)hipEventDestroy(e.c); }
   if (t->d_tile_lists) (void)hipFree(t->d_tile_lists);
   for (int h = 0; h < 2; ++h) if (t->d_macro_lists[h]) (void)hipFree(t->d_macro_lists[h]);
-  for (int h = 0; h < 2; ++h) if (t->d_regions[h]) (void)hipFree(t->d_regions[h]);
   if (t->d_tri_n) (void)hipFree(t->d_tri_n);
   if (t->d_tri) (void)hipFree(t->d_tri);
   if (t->d_tri_b) (void)hipFree(t->d_tri_b);
@@ -1094,7 +1062,6 @@ int rt_tracer_upload_spheres(rt_tracer* t, const rt_float4* spheres, size_t coun
     HIP_CHECK(hipStreamSynchronize(t->main_stream()));
     if (t->d_spheres) { (void)hipFree(t->d_spheres); t->d_spheres = nullptr; }
     t->n_spheres = 0;
-    t->list_key_valid = false;                                           // stored certain-winner verdicts assume a scene without spheres
     if (count == 0) return;
     HIP_CHECK(hipMalloc(&t->d_spheres, count * sizeof(float4)));
     HIP_CHECK(hipMemcpy(t->d_spheres, spheres, count * sizeof(float4), hipMemcpyHostToDevice));
