@@ -653,9 +653,21 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   rng.v4 = p.rng[5 * static_cast<size_t>(p.npix) + pix];
 
 
-  V3 po, pd;
-  pinhole<FMA>(p, cxp, p.row0 + cyp, po, pd);
-  const V3 focal = focal_point<FMA>(p, pd);
+  // A launch that loads its tile's stored list knows the certain-winner verdict before anything else: such a tile needs
+  // no pinhole ray either (its samples keep their RNG draws and additions only).
+  const bool sure_ok = BIN && ONEPASS && (p.flags & (TRACE_NEAREST_HIT | TRACE_NO_SURE_HIT)) == 0u && p.n_spheres == 0u && p.tri_n == nullptr;
+  bool loaded_sure = false;
+  if constexpr (BIN && ONEPASS) {
+    if ((p.flags & TRACE_LISTS_LOAD) != 0u && sure_ok) {
+      const size_t slot0 = (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 4u + wave;
+      loaded_sure = (static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(p.tile_lists[slot0 * (1u + p.bin_list)]))) >> 31) != 0u;
+    }
+  }
+  V3 po = {0.0f, 0.0f, 0.0f}, pd = {0.0f, 0.0f, 0.0f}, focal = {0.0f, 0.0f, 0.0f};
+  if (!loaded_sure) {                                               // wave-uniform
+    pinhole<FMA>(p, cxp, p.row0 + cyp, po, pd);
+    focal = focal_point<FMA>(p, pd);
+  }
 
   const uint32_t n = p.n_tris;
   // false: the reference's rule (keep the farthest t, negative t accepted, Kernels.cuh:73,84);
@@ -704,7 +716,6 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   bool lane_keep = false, lane_sure = false;      // this lane's verdicts of a one-step classification (lane = triangle)
   float lane_q[2] = {0.0f, 0.0f};
   uint32_t lane_tri = 0, class_steps = 0;
-  const bool sure_ok = BIN && ONEPASS && (p.flags & (TRACE_NEAREST_HIT | TRACE_NO_SURE_HIT)) == 0u && p.n_spheres == 0u && p.tri_n == nullptr;
   // Block-level pre-cull (scenes larger than the per-wave list): the 256 threads classify every
   // triangle ONCE against the union of the block's four tile families and keep the survivors'
   // indices, in ascending order, in LDS; each wave then only refines that short list against its
@@ -871,7 +882,7 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
       const uint32_t count = word & 0x3FFu;                          // bit 31: the tile has a certain winner, bits 10..19: its triangle
       sure_hit_tile = sure_ok && (word >> 31) != 0u;
       sure_winner = (word >> 10) & 0x3FFu;
-      for (uint32_t base = 0; base < count; base += 64u) {
+      for (uint32_t base = 0; base < (sure_hit_tile ? 0u : count); base += 64u) {   // (a certain winner needs no records)
         const uint32_t e = base + lane;
         if (e < count) {
           const uint32_t tri = saved[1u + e];
