@@ -970,7 +970,7 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       if (static_cast<uint32_t>(k) < valid_k) get_ray<FMA>(p, focal, rng, o[k], d[k]);   // :136
-      else { o[k] = po; d[k] = pd; }                               // padding ray, result discarded
+      else { o[k] = {0.0f, 0.0f, 0.0f}; d[k] = {0.0f, 0.0f, -1.0f}; }   // padding ray, result discarded (a constant: the pinhole ray need not stay live)
       best_t[k] = nearest ? FLT_MAX : -FLT_MAX;                    // :73
       best_i[k] = -1;
     }

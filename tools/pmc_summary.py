@@ -39,6 +39,23 @@ fetch_kb, write_kb = means[(tk, "FETCH_SIZE")], means[(tk, "WRITE_SIZE")]
 npix = 1920 * 1080
 alg = npix * (2 * 24 + 32) + 48 * 32
 traffic = int(round((fetch_kb * 2.0 + write_kb) * 1024))
+# C4 (optional passes): the dense-scene kernel + its macro pre-pass
+c4_traffic = {}
+f4f = sorted(glob.glob(os.path.join(src, "pmc_fetch_c4", "*", "*counter_collection.csv")), key=os.path.getmtime)
+f4w = sorted(glob.glob(os.path.join(src, "pmc_write_c4", "*", "*counter_collection.csv")), key=os.path.getmtime)
+if f4f and f4w:
+    def per_launch(path, counter):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] == counter and ("trace_kernel" in r["Kernel_Name"] or "macro_bin_kernel" in r["Kernel_Name"]):
+                agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+        return sum(2.0 * sum(v) / len(v) for v in agg.values())          # two half-frame dispatches per launch
+    f_kb, w_kb = per_launch(f4f[-1], "FETCH_SIZE"), per_launch(f4w[-1], "WRITE_SIZE")
+    alg4 = 3840 * 2160 * (2 * 24 + 32) + 48 * 10000
+    c4_traffic = {"C4": {"bytes_per_launch": int(round((f_kb * 2.0 + w_kb) * 1024)), "fetch_size_kb_raw": round(f_kb, 1), "fetch_correction": 2.0,
+                         "write_size_kb": round(w_kb, 1), "algorithmic_bytes_per_launch": alg4,
+                         "note": "trace kernel + macro_bin_kernel; above the algorithmic bytes by the spill stores of the 128-VGPR dense-scene kernel's "
+                                 "classification prologue (scratch 56 B/lane, DESIGN.md 6) and the macro / block list traffic"}}
 json.dump({
     "kernel_source_hash": khash,
     "_method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a separate pass, --pmc WRITE_SIZE around `python3 bench.py --steps 5 --warmup 1 "
@@ -46,7 +63,8 @@ json.dump({
                "(factor calibrated in round 1 on convert_kernel, profiles/r01_pmc_c3_fetch.csv). Per-kernel means: profiles/%s_c3_pmc_summary.csv." % (tag, tag),
     "C3": {"bytes_per_launch": traffic, "fetch_size_kb_raw": round(fetch_kb, 1), "fetch_correction": 2.0, "write_size_kb": round(write_kb, 1),
            "algorithmic_bytes_per_launch": alg,
-           "note": "bench launches treat the accumulators as zero (no accumulator read): reads = 24 B/pixel RNG state, writes = 24 B RNG + 16 B RGBA + 4 B count + 4 B BGRA8"}},
+           "note": "bench launches treat the accumulators as zero (no accumulator read): reads = 24 B/pixel RNG state, writes = 24 B RNG + 16 B RGBA + 4 B count + 4 B BGRA8"},
+    **c4_traffic},
     open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
 valu = means[(tk, "SQ_INSTS_VALU")]
 c4 = {}

@@ -17,5 +17,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" 
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d "$O/pmc_sq" -- $B --steps 5 --warmup 1 > "$O/pmc_sq.log" 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d "$O/pmc_sq_c4" -- $B --config C4 --steps 3 --warmup 1 > "$O/pmc_sq_c4.log" 2>&1 || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_c4" -- $B --config C4 --steps 10 --warmup 2 > "$O/stats_c4.log" 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch_c4" -- $B --config C4 --steps 3 --warmup 1 > "$O/pmc_fetch_c4.log" 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write_c4" -- $B --config C4 --steps 3 --warmup 1 > "$O/pmc_write_c4.log" 2>&1 || exit 1
 grep '^{"metric"' "$O/stats.log" > "$O/bench_c3_under_rocprof.json"
 echo "done: $O"
