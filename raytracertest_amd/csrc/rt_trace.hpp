@@ -850,21 +850,10 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
               return (__builtin_bit_cast(uint32_t, x) + 0x8000u) >> 16;
             };
             auto pk = [&](float hi, float lo) { return __builtin_bit_cast(float, (bf(hi) << 16) | bf(lo)); };
-            // The three forms are stored most-decisive first (smallest constant term = most negative at the centre of
-            // lens and tile): the sample loop evaluates them one after the other and leaves at the first one that
-            // rejects every ray of the wave -- a triangle usually misses the whole bundle on ONE side.
-            float c0[3] = {forms[0], forms[3], forms[6]}, cx[3] = {forms[1], forms[4], forms[7]}, cy[3] = {forms[2], forms[5], forms[8]};
-            float gx[3] = {forms[9], forms[12], forms[15]}, gy[3] = {forms[10], forms[13], forms[16]}, gz[3] = {forms[11], forms[14], forms[17]};
-            auto cswap = [&](int a, int b) {
-              const bool sw = c0[b] < c0[a];
-              auto ex = [&](float (&v)[3]) { const float t = sw ? v[b] : v[a]; v[b] = sw ? v[a] : v[b]; v[a] = t; };
-              ex(c0); ex(cx); ex(cy); ex(gx); ex(gy); ex(gz);
-            };
-            cswap(0, 1); cswap(1, 2); cswap(0, 1);
-            cP[4u * pos] = make_float4(c0[0], cx[0], cy[0], c0[1]);
-            cP[4u * pos + 1u] = make_float4(cx[1], cy[1], c0[2], cx[2]);
-            cP[4u * pos + 2u] = make_float4(cy[2], pk(gx[0], gy[0]), pk(gz[0], gx[1]), pk(gy[1], gz[1]));
-            cP[4u * pos + 3u] = make_float4(pk(gx[2], gy[2]), pk(gz[2], 0.0f), 0.0f, 0.0f);
+            cP[4u * pos] = make_float4(forms[0], forms[1], forms[2], forms[3]);
+            cP[4u * pos + 1u] = make_float4(forms[4], forms[5], forms[6], forms[7]);
+            cP[4u * pos + 2u] = make_float4(forms[8], pk(forms[9], forms[10]), pk(forms[11], forms[12]), pk(forms[13], forms[14]));
+            cP[4u * pos + 3u] = make_float4(pk(forms[15], forms[16]), pk(forms[17], 0.0f), 0.0f, 0.0f);
           }
         }
       }
@@ -1019,34 +1008,18 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
             const uint32_t w0 = __builtin_bit_cast(uint32_t, q2.y), w1 = __builtin_bit_cast(uint32_t, q2.z),
                            w2 = __builtin_bit_cast(uint32_t, q2.w), w3 = __builtin_bit_cast(uint32_t, q3.x),
                            w4 = __builtin_bit_cast(uint32_t, q3.y);
-            // A ray survives when all three forms are >= 0 at its lens origin.  One form after the other (stored most
-            // decisive first): per lane and candidate the constant term + gradient . (this lane's focal point - box centre),
-            // per sample two fma and a compare; the candidate is left as soon as no ray of the wave is alive.
-            unsigned long long mk[K];
-            unsigned long long alive = 0ull;
+            // per lane and candidate: constant term + gradient . (this lane's focal point - box centre)
             const float b1 = __builtin_fmaf(hi16(w1), dFz, __builtin_fmaf(lo16(w0), dFy, __builtin_fmaf(hi16(w0), dFx, f0.x)));
+            const float b2 = __builtin_fmaf(lo16(w2), dFz, __builtin_fmaf(hi16(w2), dFy, __builtin_fmaf(lo16(w1), dFx, f0.w)));
+            const float b3 = __builtin_fmaf(hi16(w4), dFz, __builtin_fmaf(lo16(w3), dFy, __builtin_fmaf(hi16(w3), dFx, f1.z)));
+            unsigned long long alive = 0ull;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
               const float F1 = __builtin_fmaf(f0.z, doy[k], __builtin_fmaf(f0.y, dox[k], b1));
-              mk[k] = __builtin_amdgcn_ballot_w64(!(F1 < 0.0f) && inside && static_cast<uint32_t>(k) < valid_k);
-              alive |= mk[k];
-            }
-            if (alive == 0ull) { if constexpr (STATS) st_pre += 1; continue; }
-            const float b2 = __builtin_fmaf(lo16(w2), dFz, __builtin_fmaf(hi16(w2), dFy, __builtin_fmaf(lo16(w1), dFx, f0.w)));
-            alive = 0ull;
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
               const float F2 = __builtin_fmaf(f1.y, doy[k], __builtin_fmaf(f1.x, dox[k], b2));
-              mk[k] &= __builtin_amdgcn_ballot_w64(!(F2 < 0.0f));
-              alive |= mk[k];
-            }
-            if (alive == 0ull) { if constexpr (STATS) st_pre += 1; continue; }
-            const float b3 = __builtin_fmaf(hi16(w4), dFz, __builtin_fmaf(lo16(w3), dFy, __builtin_fmaf(hi16(w3), dFx, f1.z)));
-            alive = 0ull;
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
               const float F3 = __builtin_fmaf(f2, doy[k], __builtin_fmaf(f1.w, dox[k], b3));
-              alive |= mk[k] & __builtin_amdgcn_ballot_w64(!(F3 < 0.0f));
+              const float worst = __builtin_fminf(__builtin_fminf(F1, F2), F3);
+              alive |= __builtin_amdgcn_ballot_w64(!(worst < 0.0f) && inside && static_cast<uint32_t>(k) < valid_k);
             }
             if (alive == 0ull) { if constexpr (STATS) st_pre += 1; continue; }
           }
