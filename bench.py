@@ -26,6 +26,7 @@ Prints ONE JSON line on rank 0 with
                 full-scan flops for context (a ratio, not a utilisation)
   gather_ms     N > 1: device time of one tile gather on the root's gather stream
   warm_lists    NOT the headline: the same steps with the library's default list reuse across Traces
+  full_path_all_tiles  NOT the headline: the same steps with certain-winner tiles switched off (every tile traces its rays)
   cpu_baseline  the oracle (scalar CPU port of the reference kernel) timed on this box's cores, N = 1 only
 """
 import argparse
@@ -215,6 +216,30 @@ def main():
                 "note": "NOT the headline: same steps with the tile candidate lists kept between Traces (library default, "
                         "rt_tracer_set_list_reuse): classification and ray-family work happen once, results identical"}
         job.tracer.SetListReuse(False)
+    full_path = None
+    if n_parts == 1 and args.config in ("C3",) and not args.no_warm:
+        # the same cold steps with every tile on the full path (RT_FLAG_NO_SURE_HIT: tiles with a certain winner generate their
+        # rays and run their tests anyway) -- what the kernel does per ray when nothing can be proven, next to the headline
+        fp = R.RayTracer((cfg["width"], cfg["height"]), (0.0, 0.0, 0.0), cfg["angles"], cfg["fov"], cfg["focal"], cfg["aperture"],
+                         seed=cfg["seed"], device=local_rank, no_sure_hit=True)
+        if tris.shape[0]:
+            fp.UploadScene(tris)
+        fp.SetListReuse(False)
+        for _ in range(max(args.warmup, 2)):
+            fp.TraceEnqueue(cfg["iterations"], cfg["samples"])
+        fp.Sync()
+        fp.KernelTime(reset=True)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            fp.TraceEnqueue(cfg["iterations"], cfg["samples"])
+        fp.Sync()
+        dt = time.perf_counter() - t1
+        fk_ms, fk_n = fp.KernelTime(reset=True)
+        fp.close()
+        full_path = {"value": round(cfg["width"] * cfg["height"] * cfg["samples"] * cfg["iterations"] * args.steps / dt / 1e6, 2), "unit": "Mray/s",
+                     "ms_per_step": round(dt / args.steps * 1e3, 5), "kernel_us": round(fk_ms / max(fk_n, 1) * 1e3, 2),
+                     "note": "NOT the headline: the same steps with RT_FLAG_NO_SURE_HIT -- every tile generates its rays and runs its tests, "
+                             "also the tiles whose winner is certain for the whole ray family (identical image)"}
     launch_info = job.tracer.Info()
     version = R.load_library().rt_version().decode()
     kernel_hash = version.split("kernels=")[-1].rstrip(")") if "kernels=" in version else None
@@ -308,6 +333,8 @@ def main():
                 out["c5_strong"] = c5
         if warm is not None:
             out["warm_lists"] = warm
+        if full_path is not None:
+            out["full_path_all_tiles"] = full_path
         if not args.no_valu and n_parts == 1 and args.config != "C5":
             # instrumented launch of the reference's own algorithm (every ray scans the whole list,
             # reference-order tests) on a scratch tracer: exit points per test
