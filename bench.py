@@ -216,6 +216,11 @@ def main():
                 "note": "NOT the headline: same steps with the tile candidate lists kept between Traces (library default, "
                         "rt_tracer_set_list_reuse): classification and ray-family work happen once, results identical"}
         job.tracer.SetListReuse(False)
+    launch_info = job.tracer.Info()
+    version = R.load_library().rt_version().decode()
+    kernel_hash = version.split("kernels=")[-1].rstrip(")") if "kernels=" in version else None
+    job.close(destroy_group=False)
+
     full_path = None
     if n_parts == 1 and args.config in ("C3",) and not args.no_warm:
         # the same cold steps with every tile on the full path (RT_FLAG_NO_SURE_HIT: tiles with a certain winner generate their
@@ -240,11 +245,6 @@ def main():
                      "ms_per_step": round(dt / args.steps * 1e3, 5), "kernel_us": round(fk_ms / max(fk_n, 1) * 1e3, 2),
                      "note": "NOT the headline: the same steps with RT_FLAG_NO_SURE_HIT -- every tile generates its rays and runs its tests, "
                              "also the tiles whose winner is certain for the whole ray family (identical image)"}
-    launch_info = job.tracer.Info()
-    version = R.load_library().rt_version().decode()
-    kernel_hash = version.split("kernels=")[-1].rstrip(")") if "kernels=" in version else None
-    job.close(destroy_group=False)
-
     # N > 1: the strong-scaling record of BASELINE configs[4] beside the weak headline
     c5 = None
     if n_parts > 1 and args.config == "C3" and not args.no_c5:
