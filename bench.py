@@ -17,6 +17,10 @@ configs[4], the 10k-triangle scene at 3840x2160x256 spp as ONE frame in N row ba
 fewer devices than N (a 1-GPU box), the single-process form places the bands round-robin on what is
 there and says so (`config.devices`).
 
+Before the W warmup steps every device is brought to its steady clocks with the VALU calibration loop of the `valu`
+record (`clock_preheat`, 150 ms, no step of the path in it: a cold MI355X needs ~25 ms of load to ramp, which is longer than
+a short run's whole timed region; tools/clock_ramp.py, --no-preheat).
+
 Prints ONE JSON line on rank 0 with
   roofline      HBM: algorithmic bytes per launch / live HIP-event kernel time vs 8 TB/s (contractual
                 bound), frac_wall = the same bytes / wall time per step, and the R = 48 accounting beside it
@@ -42,6 +46,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak (spec)
 RNG_STATE_BYTES = 24           # persisted per pixel: d + v[5] (the reference's curandState_t is 48)
+PREHEAT_MS = 150.0             # VALU calibration loop before the warmup steps (see preheat())
 FLOP_BY_EXIT = (20, 30, 46, 52)   # culled at det / rejected at u / at v / full
 FLOP_PER_RAY_SETUP = 100          # ray generation + shading, per ray
 
@@ -109,6 +114,33 @@ def cpu_baseline(cfg, tris, spheres, rows, threads):
                       % (rows, cfg["width"], H, row0, row0 + rows - 1, launches, cfg["samples"], rays, dt, dt * threads)}
 
 
+def preheat(devices, min_ms=PREHEAT_MS):
+    """Bring the devices to their steady clocks before the warmup steps: the VALU calibration loop of the `valu` record
+    (rt_dbg_valu_peak, ~3 ms per run) repeated for min_ms on every device at once.  tools/clock_ramp.py: from a cold process
+    a C3 step takes 118 us and reaches its steady 98.5 us only after ~250 steps (25 ms of load) -- longer than the whole
+    timed region of a short run -- and after 70 ms of this loop the first steps are at the steady value.  No step of the
+    path runs here.  Returns {device: (lane_fma_per_s, clock_ghz, ms)} of each device's last run."""
+    import threading
+    from raytracertest_amd import api
+    out = {}
+
+    def run(dev):
+        t0 = time.perf_counter()
+        while True:
+            lane_fma, ghz = api.dbg_valu_peak(dev)
+            ms = (time.perf_counter() - t0) * 1e3
+            if ms >= min_ms:
+                break
+        out[dev] = (lane_fma, ghz, ms)
+
+    threads = [threading.Thread(target=run, args=(d,)) for d in sorted(set(devices))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    return out
+
+
 def timed_steps(job, steps, warmup):
     """W untimed steps, then exactly K steps bracketed by (device drain + barrier) on both sides; MAX over ranks."""
     for _ in range(warmup):
@@ -154,6 +186,7 @@ def main():
     ap.add_argument("--no-valu", action="store_true", help="skip the instrumented launch + VALU calibration")
     ap.add_argument("--no-warm", action="store_true", help="skip the extra warm_lists measurement (profiling runs: headline launches only)")
     ap.add_argument("--no-c5", action="store_true", help="N > 1: skip the c5_strong record")
+    ap.add_argument("--no-preheat", action="store_true", help="start the warmup steps on a cold device (clocks not ramped)")
     ap.add_argument("--samples-in-flight", type=int, default=0)
     ap.add_argument("--lds-chunk", type=int, default=0)
     args = ap.parse_args()
@@ -192,6 +225,7 @@ def main():
     # Headline: every step is a from-scratch Trace pass -- the tile candidate lists (a camera-dependent
     # acceleration structure the library keeps between Traces by default) are NOT carried from step to step.
     job.tracer.SetListReuse(False)
+    heat = {} if args.no_preheat else preheat(devices if devices else [local_rank])
     res = timed_steps(job, args.steps, args.warmup)
     elapsed, kernel_ms, launches = res["elapsed"], res["kernel_ms"], res["launches"]
     bands = job.tracer.Bands()
@@ -297,6 +331,11 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 5),
             "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
+            "clock_preheat": ({"ms": round(max(h[2] for h in heat.values()), 1), "clock_ghz": round(min(h[1] for h in heat.values()), 3),
+                               "note": "before the W warmup steps every device ran the VALU calibration loop of the valu record for this long, so "
+                                       "that the timed steps run at the device's steady clocks (tools/clock_ramp.py: a cold device needs ~250 "
+                                       "steps = 25 ms of load to get there); no step of the path runs in it; --no-preheat turns it off"}
+                              if heat else None),
             "config": {"workload": WORKLOADS[args.config],
                        "image": "%dx%d per GPU (row band of a %dx%d frame)" % (
                            cfg["width"], band0_rows, cfg["width"], cfg["height"] * (n_parts if weak else 1)),
@@ -350,7 +389,7 @@ def main():
             exits = [st["exit_det"], st["exit_u"], st["exit_v"], st["exit_hit"]]
             scale = cfg["samples"] / st_samples
             flop = scale * sum(f * e for f, e in zip(FLOP_BY_EXIT, exits)) + FLOP_PER_RAY_SETUP * rays_band0
-            lane_fma, ghz = api.dbg_valu_peak(local_rank)
+            lane_fma, ghz = heat[local_rank][:2] if local_rank in heat else api.dbg_valu_peak(local_rank)
             rate_peak = lane_fma / 64.0                      # wave64 VALU instructions per second, whole device
             tf = flop / avg_kernel_s / 1e12
             issued, issued_stale = stamped(os.path.join(ROOT, "profiles", "valu_issue.json"), args.config, kernel_hash)

@@ -852,7 +852,19 @@ int rt_tracer_create_ex(const uint32_t imageSize[2], const float cameraPosition[
   rc = guarded(t, [&] {
     t->use_device();
     HIP_CHECK(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
-    HIP_CHECK(hipStreamCreateWithFlags(&t->stream_b, hipStreamNonBlocking));
+    // The runtime maps streams onto a few hardware queues.  The two streams of the first tracer of a process get queues
+    // of their own; a tracer created while another one is alive on the device was measured 20 % slower (its two
+    // half-frame kernels serialise on one queue; tools/placement_probe.py).  RT_MI355X_STREAM_PRIO=1 creates the second
+    // stream at high priority, which gives such a tracer its concurrency back (172 -> 153 us) but costs the first
+    // tracer 7 % (145 vs 135 us), so it is opt-in; GPU_MAX_HW_QUEUES=8 in the environment cures both.
+    {
+      const char* sp = getenv("RT_MI355X_STREAM_PRIO");
+      int lo = 0, hi = 0;
+      if (sp && sp[0] == '1' && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
+        HIP_CHECK(hipStreamCreateWithPriority(&t->stream_b, hipStreamNonBlocking, hi));
+      else
+        HIP_CHECK(hipStreamCreateWithFlags(&t->stream_b, hipStreamNonBlocking));
+    }
     HIP_CHECK(hipEventCreateWithFlags(&t->handoff_event, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&t->join_event, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&t->fork_event, hipEventDisableTiming));
