@@ -286,6 +286,12 @@ int rt_dbg_check_midrange(int device, uint64_t out[4]);
 /* The stored tile candidate lists of a small-scene tracer (after a launch that stored them): per 8x8 wave tile, in grid
  * order (4 per 32x8 block), *words_per_tile words: count | winner << 10 | certain-winner << 31, then the triangle indices. */
 int rt_dbg_read_tile_lists(rt_tracer* t, uint32_t* dst, size_t capacity_words, uint32_t* words_per_tile);
+/* The focal box each 8x8 wave tile of a trace launch classifies with (full tiles: the four corner pixels' focal points
+ * widened by a curvature term; partial tiles: every in-image lane) and the focal points of the band's pixels as the rays
+ * use them.  boxes: 8 floats per tile in grid order (4 per 32x8 block): lo[3], hi[3], corner path taken, usable;
+ * focal: 3 floats per pixel.  curv_scale multiplies the curvature term for THIS launch only (1 = product; the test's
+ * teeth: with 0 some pixel's focal point must fall outside its box). */
+int rt_dbg_focal_boxes(rt_tracer* t, float curv_scale, float* boxes, size_t boxes_capacity, float* focal, size_t focal_capacity);
 /* states n*6 {d,v0..v4} advanced in place, out n*m uniforms in (0,1] */
 int rt_dbg_uniform(int device, uint32_t n, uint32_t m, uint32_t* states, float* out);
 /* thin-lens rays of the tracer's current camera for n (x, y) pixels with given RNG states */

@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "rt_dbg_rng_init_host",
     "rt_tracer_create_multi", "rt_group_unique_id", "rt_tracer_join_group", "rt_tracer_leave_group",
     "rt_tracer_gather_time", "rt_tracer_band_count", "rt_tracer_band_info",
-    "rt_tracer_join_group_bands", "rt_balance_rows", "rt_tracer_rebalance", "rt_tracer_set_band", "rt_dbg_read_tile_lists",
+    "rt_tracer_join_group_bands", "rt_balance_rows", "rt_tracer_rebalance", "rt_tracer_set_band", "rt_dbg_read_tile_lists", "rt_dbg_focal_boxes",
 ]
 
 
@@ -180,6 +180,7 @@ def load_library():
         L.rt_tracer_rebalance.argtypes = [vp]
         L.rt_tracer_set_band.argtypes = [vp, C.c_uint32, C.c_uint32]
         L.rt_dbg_read_tile_lists.argtypes = [vp, u32p, C.c_size_t, u32p]
+        L.rt_dbg_focal_boxes.argtypes = [vp, C.c_float, f32p, C.c_size_t, f32p, C.c_size_t]
         _lib = L
         return _lib
 
@@ -454,6 +455,14 @@ class RayTracer:
         w = int(wpt[0])
         words = buf[:bx * by * 4 * w].reshape(by, bx * 4, w)[:, :, 0]
         return (words & 0x3FF).astype(np.int32), ((words >> 10) & 0x3FF).astype(np.int32), (words >> 31).astype(bool)
+
+    def DebugFocalBoxes(self, curv_scale=1.0):
+        """(boxes (tiles_y, tiles_x, 8): lo[3], hi[3], corner path, usable; focal (rows, width, 3)) of a trace launch's tiles."""
+        bx, by = (self.width + 31) // 32, (self.rows + 7) // 8
+        boxes = np.zeros((by, bx * 4, 8), np.float32)
+        focal = np.zeros((self.rows, self.width, 3), np.float32)
+        self._check(self._lib.rt_dbg_focal_boxes(self._h, float(curv_scale), _f32p(boxes), boxes.size, _f32p(focal), focal.size))
+        return boxes, focal
 
     def DebugGetRay(self, pixels, states):
         pix = np.ascontiguousarray(pixels, np.uint32).reshape(-1, 2)

@@ -125,6 +125,34 @@ __global__ void dbg_get_ray_kernel(const TraceParams p, uint32_t n, const uint32
   s[0] = r.d; s[1] = r.v0; s[2] = r.v1; s[3] = r.v2; s[4] = r.v3; s[5] = r.v4;
 }
 
+// The focal box every wave tile of a trace launch would classify with (focal_bounds: four corner pixels + curvature for
+// full tiles, all in-image lanes otherwise) next to the focal points of its pixels, for the test that the box holds them
+// all.  Same grid as the trace kernel.  boxes[tile][8] = lo[3], hi[3], corner path taken, usable; focal[pixel of the band][3].
+template <bool FMA>
+__global__ __launch_bounds__(256) void dbg_focal_boxes_kernel(const TraceParams p, float* __restrict__ boxes, float* __restrict__ focal_out) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t px = blockIdx.x * 32u + wave * 8u + (lane & 7u);
+  const uint32_t ly = blockIdx.y * 8u + (lane >> 3);
+  const bool inside = px < p.W && ly < p.rows;
+  const uint32_t cxp = inside ? px : 0u, cyp = inside ? ly : 0u;
+  V3 po, pd;
+  pinhole<FMA>(p, cxp, p.row0 + cyp, po, pd);
+  const V3 f = focal_point<FMA>(p, pd);
+  const FocalBounds b = focal_bounds(p, f, inside);
+  const bool corner_path = p.tile_curv > 0.0f && __builtin_amdgcn_ballot_w64(inside) == ~0ull;
+  if (inside) {
+    float* o = focal_out + 3u * (static_cast<size_t>(ly) * p.W + px);
+    o[0] = f.x; o[1] = f.y; o[2] = f.z;
+  }
+  if (lane == 0u) {
+    float* o = boxes + 8u * ((static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 4u + wave);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { o[i] = b.lo[i]; o[3 + i] = b.hi[i]; }
+    o[6] = corner_path ? 1.0f : 0.0f;
+    o[7] = (b.ok && b.any) ? 1.0f : 0.0f;
+  }
+}
+
 // fp32 VALU calibration: 8 independent fma chains per lane, 16x unrolled.  Measures the
 // attainable lane-FMA rate of THIS device under load (the honest denominator of the trace
 // kernel's VALU roofline) and the clock it holds (s_memtime ticks / 100 MHz realtime).
@@ -332,6 +360,13 @@ hipError_t launch_dbg_get_ray(bool fma, const TraceParams& p, uint32_t n, const 
   if (n == 0) return hipSuccess;
   if (fma) hipLaunchKernelGGL(dbg_get_ray_kernel<true>, dim3(cdiv(n, 64)), dim3(64), 0, st, p, n, pixels, states, rays);
   else hipLaunchKernelGGL(dbg_get_ray_kernel<false>, dim3(cdiv(n, 64)), dim3(64), 0, st, p, n, pixels, states, rays);
+  return hipGetLastError();
+}
+
+hipError_t launch_dbg_focal_boxes(bool fma, const TraceParams& p, float* boxes, float* focal, hipStream_t st) {
+  const dim3 grid(cdiv(p.W, 32), cdiv(p.rows, 8));
+  if (fma) hipLaunchKernelGGL(dbg_focal_boxes_kernel<true>, grid, dim3(256), 0, st, p, boxes, focal);
+  else hipLaunchKernelGGL(dbg_focal_boxes_kernel<false>, grid, dim3(256), 0, st, p, boxes, focal);
   return hipGetLastError();
 }
 

@@ -18,6 +18,10 @@ struct TraceParams {
   uint32_t  samples;   // sampleCount of this launch
   float     cam[12];   // mCameraTransformation: xyz of the 4 columns
   float     half_height, aspect, focal, aperture;
+  // full 8x8 tiles bound their focal points from the four corner pixels (focal_bounds): tile_curv >= the distance, per
+  // component, between a focal point of the tile and the bilinear interpolant of the corners' (host, params());
+  // tile_round = the magnitude the rounding allowance of that bound scales with.  tile_curv <= 0: bound over all 64 lanes.
+  float     tile_curv, tile_round;
   const float4* tri_a;      // 2 float4 per triangle: (e2.xyz, e1.x), (e1.yz, v0.xy); e1 = v1-v0, e2 = v2-v0
   const float*  tri_b;      // 1 float per triangle: v0.z
   const float4* tri_color;  // abs(normalize(cross(e1,e2)))
@@ -80,6 +84,7 @@ hipError_t launch_dbg_hit_triangle(bool fma, uint32_t n, const float* rays, cons
 bool trace_can_fuse(bool filter, bool bin);      // launches with TraceParams::iters > 1 are available
 hipError_t launch_macro_bin(const TraceParams& p, bool fma, hipStream_t st);
 hipError_t launch_dbg_check_midrange(unsigned long long* out, hipStream_t st);
+hipError_t launch_dbg_focal_boxes(bool fma, const TraceParams& p, float* boxes, float* focal, hipStream_t st);
 hipError_t launch_dbg_valu_peak(uint32_t blocks, int iters, float* out, unsigned long long* clk, hipStream_t st);
 hipError_t launch_dbg_sincos(uint32_t n, const float* x, float* s, float* c, hipStream_t st);
 hipError_t launch_dbg_uniform(uint32_t n, uint32_t m, uint32_t* states, float* out, hipStream_t st);

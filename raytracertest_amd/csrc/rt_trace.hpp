@@ -305,15 +305,31 @@ struct FocalBounds {
   bool any;               // the wave has at least one in-image lane
 };
 
-__device__ __forceinline__ FocalBounds focal_bounds(V3 focal, bool inside) {
+__device__ __forceinline__ FocalBounds focal_bounds(const TraceParams& p, V3 focal, bool inside) {
   FocalBounds b;
   const float fl[3] = {focal.x, focal.y, focal.z};
   bool finite = true;
+  // A full tile (lane = x + 8 y) takes the bounds from its four corner pixels' focal points -- computed exactly as the
+  // rays use them, like every lane's -- widened by what a focal point of the tile can lie off the corners' bilinear
+  // interpolant (p.tile_curv, host) and by the roundings of the lanes' own evaluations (cx, cy, the matrix product, the
+  // exact normalize, the fma: < 1e-6 (|focal| (1 + |cx| + |cy|) + |pos|) between a lane and the ideal function, twice): 12
+  // v_readlane instead of six 6-step wave reductions.  Partial tiles (image edge) and cameras the host does not vouch for
+  // (p.tile_curv <= 0) reduce over their in-image lanes.
+  const bool corners = p.tile_curv > 0.0f && __builtin_amdgcn_ballot_w64(inside) == ~0ull;      // wave-uniform
+  const float dev = p.tile_curv + RT_SLK(4e-6f) * p.tile_round;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     finite = finite && (__builtin_fabsf(fl[i]) <= FLT_MAX);         // false for NaN/inf
-    b.lo[i] = uniform(wave_min(inside ? fl[i] : FLT_MAX));          // out-of-image lanes do not constrain
-    b.hi[i] = uniform(wave_max(inside ? fl[i] : -FLT_MAX));
+    if (corners) {
+      const int v = __builtin_bit_cast(int, fl[i]);
+      const float c0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 0)), c1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 7));
+      const float c2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 56)), c3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 63));
+      b.lo[i] = fminf(fminf(c0, c1), fminf(c2, c3)) - dev;
+      b.hi[i] = fmaxf(fmaxf(c0, c1), fmaxf(c2, c3)) + dev;
+    } else {
+      b.lo[i] = uniform(wave_min(inside ? fl[i] : FLT_MAX));        // out-of-image lanes do not constrain
+      b.hi[i] = uniform(wave_max(inside ? fl[i] : -FLT_MAX));
+    }
   }
   b.ok = __builtin_amdgcn_ballot_w64(inside && !finite) == 0ull;
   b.any = __builtin_amdgcn_ballot_w64(inside) != 0ull;
@@ -745,7 +761,7 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
     wb.ok = false; wb.any = false;
 #pragma unroll
     for (int i = 0; i < 3; ++i) { wb.lo[i] = 0.0f; wb.hi[i] = 0.0f; }
-    if (!lists_loaded) wb = focal_bounds(focal, inside);
+    if (!lists_loaded) wb = focal_bounds(p, focal, inside);
     tl_mark(9);
     if (!lists_loaded) fam = make_family(p, wb);
     else fam.usable = false;

@@ -281,6 +281,45 @@ struct rt_tracer {
     HIP_CHECK(hipMemcpyAsync(target, d_image, static_cast<size_t>(npix()) * sizeof(uint32_t), hipMemcpyDeviceToDevice, main_stream()));
   }
 
+  // Focal points of a full 8x8 tile from its four corner pixels.  F = pos + focal * d, d = M q / |M q|, q = (cx, cy, -1)
+  // affine in the pixel (ThinLensCamera.cuh:116-128).  Along an axis direction h the second derivative of x -> M x / |M x|
+  // at q is ((3 c^2 - 1) u - 2 c h') |h'|^2 / |M q|^2 (u = M q / |M q|, h' = M h / |M h|, c = u.h'), of norm
+  // <= 4 smax^2 / (smin^2 |q|^2) <= 4 lmax / lmin with lmax, lmin bounds of the eigenvalues of M^T M (Gershgorin; 1 for the
+  // rotation the camera builds) and |q| >= 1.  A bilinear interpolant over a rectangle of sides a x b is off by at most
+  // (a^2 sup|f_xx| + b^2 sup|f_yy|) / 8 in every direction, and its extremes are at the corners; cx, cy are monotone in the
+  // pixel index (rounded operations are monotone), so the corner pixels bound the rectangle.  Evaluated in double, rounded up.
+  void tile_corner_bound(rtk::TraceParams& p) const {
+    p.tile_curv = -1.0f; p.tile_round = 0.0f;
+    double G[3][3];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        G[i][j] = 0.0;
+        for (int r = 0; r < 3; ++r) G[i][j] += static_cast<double>(p.cam[i * 3 + r]) * static_cast<double>(p.cam[j * 3 + r]);
+      }
+    double lmax = 0.0, lmin = 1e300;
+    for (int i = 0; i < 3; ++i) {
+      const double off = std::fabs(G[i][(i + 1) % 3]) + std::fabs(G[i][(i + 2) % 3]);
+      lmax = std::max(lmax, G[i][i] + off);
+      lmin = std::min(lmin, G[i][i] - off);
+    }
+    if (!(lmin > 0.25) || !(lmax < 4.0)) return;                       // not a (near-)rotation: every lane bounds
+    const double hh = std::fabs(static_cast<double>(p.half_height)), asp = std::fabs(static_cast<double>(p.aspect));
+    const double a = 7.0 * 2.0 * hh * asp / static_cast<double>(W), b = 7.0 * 2.0 * hh / static_cast<double>(H);
+    // worth it only where the curvature term is small against the tile itself (<= 10 % of its smaller side: 1080p at
+    // 70 degrees is 0.9 %); coarse wide-angle frames keep the exact range of their lanes
+    if (!(0.5 * (a * a + b * b) * (lmax / lmin) <= 0.1 * std::min(a, b))) return;
+    const double foc = std::fabs(static_cast<double>(p.focal));
+#ifndef RT_TILE_CURV_SCALE          // teeth test of the adversarial campaign only (profiles/r02_boundary_campaign.txt)
+#define RT_TILE_CURV_SCALE 1.0
+#endif
+    const double curv = foc * 0.5 * (a * a + b * b) * (lmax / lmin) * 1.001 * RT_TILE_CURV_SCALE + 1e-30;
+    const double pos = std::max(std::fabs(p.cam[9]), std::max(std::fabs(p.cam[10]), std::fabs(p.cam[11])));
+    const double round = foc * (1.0 + hh * asp + hh) + pos;
+    if (!(curv <= 1e30) || !(round <= 1e30)) return;                   // NaN / inf lens: every lane bounds
+    p.tile_curv = std::nextafter(static_cast<float>(curv), 3.0e38f);
+    p.tile_round = std::nextafter(static_cast<float>(round), 3.0e38f);
+  }
+
   rtk::TraceParams params(uint32_t samples) {
     rtk::TraceParams p;
     memset(&p, 0, sizeof p);
@@ -293,6 +332,7 @@ struct rt_tracer {
     p.half_height = c.tan_half_fov();
     p.aspect = static_cast<float>(W) / static_cast<float>(H);            // ThinLensCamera.cuh:113
     p.focal = c.focal; p.aperture = c.aperture;
+    tile_corner_bound(p);
     p.tri_a = d_tri; p.tri_b = d_tri_b; p.tri_color = d_tri_color; p.n_tris = n_tris;
     p.tri_n = smooth_normals ? d_tri_n : nullptr;
     p.stats = nullptr;
@@ -1572,6 +1612,26 @@ int rt_dbg_get_ray(rt_tracer* t, uint32_t n, const uint32_t* pixels, uint32_t* s
     HIP_CHECK(hipStreamSynchronize(t->main_stream()));
     HIP_CHECK(hipMemcpy(states, ds.p, n * 6 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(rays, dr.p, n * 6 * sizeof(float), hipMemcpyDeviceToHost));
+  });
+}
+
+int rt_dbg_focal_boxes(rt_tracer* t, float curv_scale, float* boxes, size_t boxes_capacity, float* focal, size_t focal_capacity) {
+  if (!t || t->mg || !boxes || !focal) return RT_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(t->api_mu);
+  return guarded(t, [&] {
+    t->cancel_and_join();
+    t->use_device();
+    rtk::TraceParams p = t->params(1);
+    if (p.tile_curv > 0.0f) p.tile_curv = std::max(p.tile_curv * curv_scale, 1e-30f);   // this launch only; the corner path stays on (the test's teeth: 0 must fail)
+    const size_t tiles = static_cast<size_t>((t->W + 31u) / 32u) * ((t->rows + 7u) / 8u) * 4u;
+    const size_t nb = tiles * 8u, nf = static_cast<size_t>(t->npix()) * 3u;
+    if (nb > boxes_capacity || nf > focal_capacity) throw HipFail{fmt("focal boxes need %zu + %zu floats", nb, nf)};
+    DevBuf db(nb * sizeof(float)), df(nf * sizeof(float));
+    HIP_CHECK(hipMemsetAsync(db.p, 0, nb * sizeof(float), t->main_stream()));
+    HIP_CHECK(rtk::launch_dbg_focal_boxes(t->fma, p, db.as<float>(), df.as<float>(), t->main_stream()));
+    HIP_CHECK(hipStreamSynchronize(t->main_stream()));
+    HIP_CHECK(hipMemcpy(boxes, db.p, nb * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(focal, df.p, nf * sizeof(float), hipMemcpyDeviceToHost));
   });
 }
 

@@ -4,7 +4,7 @@ the per-sample forms, the wave-uniform early-outs of test_triangle).
 The classification may drop a triangle for a whole tile only when interval bounds prove that every ray of the
 tile's family misses it; a wrong "miss" silently changes a picture.  Uniformly random scenes rarely sit on a
 decision boundary, so this generator aims at them.  For a camera and a frame it picks rays of the family --
-tile-corner pixels, lens samples on the rim of the aperture or at its centre -- and builds triangles
+tile-corner (and edge-midpoint) pixels, lens samples on the rim of the aperture or at its centre -- and builds triangles
 
   edge      a point of the ray lies exactly on an edge or a vertex (u = 0, v = 0, u + v = 1), then every
             coordinate is moved by 0, 1, 2, 4, 16 or 64 ulp at most: hit/miss of that ray flips inside the family;
@@ -76,8 +76,16 @@ def _pick_ray(rng, cam, W, H):
     tx, ty = rng.integers(0, (W + 7) // 8), rng.integers(0, (H + 7) // 8)
     px = min(W - 1, tx * 8 + (0 if corner & 1 else 7))
     py = min(H - 1, ty * 8 + (0 if corner & 2 else 7))
-    if rng.integers(0, 4) == 0:
+    pick = rng.integers(0, 4)
+    if pick == 0:
         px, py = int(rng.integers(0, W)), int(rng.integers(0, H))
+    elif pick == 1:
+        # the middle of a tile edge (or of the tile): where the focal points of the tile lie farthest off the bilinear
+        # interpolant of its four corner pixels' -- full tiles bound their family from those corners plus a curvature term
+        mid = [3, 4][int(rng.integers(0, 2))]
+        edge = [0, 7, 3, 4][int(rng.integers(0, 4))]
+        ox, oy = (mid, edge) if rng.integers(0, 2) else (edge, mid)
+        px, py = min(W - 1, tx * 8 + ox), min(H - 1, ty * 8 + oy)
     if rng.integers(0, 3) == 0:
         lens = (0.0, 0.0)
     else:

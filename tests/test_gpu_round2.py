@@ -309,6 +309,52 @@ def test_get_ray_on_device_equals_oracle_camera(rt, orc, mode):
         g.close()
 
 
+# ------------------------------------------------------------------ the tile family's focal box
+@pytest.mark.parametrize("mode", [0, 1])
+def test_focal_box_of_every_tile_holds_the_focal_points_of_its_pixels(rt, mode):
+    """Full 8x8 tiles take their focal box from the four corner pixels' focal points plus a curvature term
+    (csrc/rt_trace.hpp focal_bounds, rt_tracer.hip tile_corner_bound): the box must hold the focal point of every pixel
+    of the tile exactly as the rays use it (rt_dbg_focal_boxes returns both), it must not be much wider than their
+    range, partial tiles must still take the range of their in-image lanes, and -- the test's teeth -- with the
+    curvature term scaled to 0 some pixel's focal point must lie outside its box."""
+    rng = np.random.default_rng(11 + mode)
+    cases = [((24, 24), 0, 0, (0.0, 0.0), 90.0, 3.0), ((1920, 1080), 0, 0, (0.0, 0.0), 70.0, 3.0),
+             ((333, 77), 0, 0, (0.4, -2.0), 149.0, 0.25), ((64, 100), 200, 56, (3.0, 1.0), 5.0, 1e4),
+             ((40, 40), 0, 0, (-1.3, 0.2), 120.0, 1e-3)]
+    for _ in range(25):
+        W, H = int(rng.integers(8, 200)), int(rng.integers(8, 120))
+        cases.append(((W, H), 0, 0, (float(rng.uniform(-3.2, 3.2)), float(rng.uniform(-3.2, 3.2))), float(rng.uniform(5, 150)),
+                      float(10.0 ** rng.uniform(-3, 4))))
+    broke_without_curvature = n_corner = 0
+    for (W, H), full_h, row0, angles, fov, focal in cases:
+        g = rt.RayTracer((W, H), (0, 0, 0), angles, fov, focal, focal * 0.01, seed=1, math_mode=mode, full_height=full_h, row_begin=row0)
+        boxes, F = g.DebugFocalBoxes()
+        boxes0, _ = g.DebugFocalBoxes(curv_scale=0.0)
+        g.close()
+        assert np.isfinite(F).all()
+        for ty in range((H + 7) // 8):
+            for tx in range((W + 7) // 8):
+                f = F[ty * 8:ty * 8 + 8, tx * 8:tx * 8 + 8].reshape(-1, 3)
+                b = boxes[ty, tx]
+                a = 14.0 * np.tan(np.radians(fov) / 2.0) / (full_h or H)     # the tile's sides in image-plane units (both)
+                full = f.shape[0] == 64 and a <= 0.099            # corner path: full tiles whose curvature term is < 10 % of a side
+                if f.shape[0] < 64 or a < 0.099 or a > 0.101:
+                    assert b[7] == 1.0 and b[6] == (1.0 if full else 0.0), (W, H, tx, ty, b)
+                else:
+                    full = b[6] == 1.0
+                lo, hi = f.min(axis=0), f.max(axis=0)
+                assert (b[0:3] <= lo).all() and (hi <= b[3:6]).all(), (W, H, fov, focal, tx, ty, b, lo, hi)
+                if full:
+                    # not much wider than the range: the curvature term is second order in the tile's angular size
+                    assert ((lo - b[0:3]) <= focal * (1.1 * a * a + 1e-4)).all() and ((b[3:6] - hi) <= focal * (1.1 * a * a + 1e-4)).all()
+                    b0 = boxes0[ty, tx]
+                    n_corner += 1
+                    broke_without_curvature += int(not ((b0[0:3] <= lo).all() and (hi <= b0[3:6]).all()))
+                else:
+                    assert np.array_equal(b[0:3], lo) and np.array_equal(b[3:6], hi)
+    assert n_corner > 1000 and broke_without_curvature >= 10, (n_corner, broke_without_curvature)
+
+
 # ------------------------------------------------------------------ classification at its decision boundaries
 def test_adversarial_boundary_campaign_default_kernel_equals_plain_full_scan(rt):
     """tools/stress_boundaries.py: 300 scenes built by tests/adversarial.py -- triangles with an edge or a vertex on a
