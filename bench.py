@@ -220,8 +220,18 @@ def main():
     n_tris = tris.shape[0] // 3
     weak = args.config != "C5"
 
-    job = RowBandJob(cfg, tris, spheres, world=world, rank=rank, local_rank=local_rank, weak=weak, devices=devices,
-                     samples_in_flight=args.samples_in_flight, lds_chunk=args.lds_chunk)
+    try:
+        job = RowBandJob(cfg, tris, spheres, world=world, rank=rank, local_rank=local_rank, weak=weak, devices=devices,
+                         samples_in_flight=args.samples_in_flight, lds_chunk=args.lds_chunk)
+    except Exception as e:
+        # a sharded job that cannot be set up (device missing, RCCL communicator not formed) must end the run with a
+        # reason, not leave ranks blocked in a collective: say why on every rank, one JSON line on rank 0, hard exit
+        sys.stderr.write("bench.py rank %d: %s: %s\n" % (rank, type(e).__name__, e))
+        if rank == 0:
+            print(json.dumps({"metric": "Mray/s at %dx%dx%dspp" % (cfg["width"], cfg["height"], cfg["samples"]), "value": None,
+                              "unit": "Mray/s", "n_gpus": n_parts, "error": "%s: %s" % (type(e).__name__, e)}), flush=True)
+        sys.stderr.flush()
+        os._exit(2)
     # Headline: every step is a from-scratch Trace pass -- the tile candidate lists (a camera-dependent
     # acceleration structure the library keeps between Traces by default) are NOT carried from step to step.
     job.tracer.SetListReuse(False)

@@ -138,7 +138,26 @@ class NativeExchange:
             uid[0] = group_unique_id()
         if job.world > 1:
             job.dist.broadcast_object_list(uid, src=0)      # 128 bytes through the launcher's rendezvous
-        job.tracer.JoinGroup(job.world, job.rank, uid[0], row_begin=row_begin)
+        # The join is collective (ncclCommInitRank): a rank that cannot reach the others would block in it for ever.
+        # It runs on a helper thread so that this one can give up with a message instead (RT_MI355X_JOIN_TIMEOUT seconds).
+        import os
+        import threading
+        done, failure = threading.Event(), []
+
+        def join():
+            try:
+                job.tracer.JoinGroup(job.world, job.rank, uid[0], row_begin=row_begin)
+            except Exception as e:                          # handed to the waiting thread
+                failure.append(e)
+            done.set()
+
+        threading.Thread(target=join, daemon=True).start()
+        limit = float(os.environ.get("RT_MI355X_JOIN_TIMEOUT", "300"))
+        if not done.wait(limit):
+            raise TimeoutError("rank %d: rt_tracer_join_group did not return within %.0f s (RCCL communicator of %d ranks)"
+                               % (job.rank, limit, job.world))
+        if failure:
+            raise failure[0]
 
     def detach(self, job):
         job.tracer.LeaveGroup()
