@@ -14,12 +14,12 @@ for line in open(path):
         if re.match(r"^_Z\w*%s\w*:" % re.escape(want), line):
             inside = True
         continue
+    if line.startswith(".Lfunc_end"):                # (blocks may be placed behind the first s_endpgm)
+        break
     m = re.match(r"^\s+([a-z_0-9]+)\s", line)
     if not m:
         continue
     op = m.group(1)
-    if op == "s_endpgm":
-        break
     key = ("ds_bpermute" if op.startswith("ds_bpermute") else "v_readlane/readfirstlane" if op.startswith("v_read") else
            "valu" if op.startswith("v_") else "salu" if op.startswith("s_") else "lds" if op.startswith("ds_") else
            "vmem" if op.startswith(("global_", "buffer_", "scratch_", "flat_")) else "other")
