@@ -29,6 +29,8 @@ Prints ONE JSON line on rank 0 with
                 issue rate this device sustains (calibrated live); `algorithmic` = the reference's
                 full-scan flops for context (a ratio, not a utilisation)
   gather_ms     N > 1: device time of one tile gather on the root's gather stream
+  c5_strong     N > 1: the strong-scaling record; measured after the headline under a watchdog (RT_MI355X_C5_TIMEOUT, 300 s):
+                if it or the final barrier blocks, rank 0 still prints the line, with the reason in c5_strong.error
   warm_lists    NOT the headline: the same steps with the library's default list reuse across Traces
   full_path_all_tiles  NOT the headline: the same steps with certain-winner tiles switched off (every tile traces its rays)
   cpu_baseline  the oracle (scalar CPU port of the reference kernel) timed on this box's cores, N = 1 only
@@ -37,6 +39,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -289,8 +292,154 @@ def main():
                      "ms_per_step": round(dt / args.steps * 1e3, 5), "kernel_us": round(fk_ms / max(fk_n, 1) * 1e3, 2),
                      "note": "NOT the headline: the same steps with RT_FLAG_NO_SURE_HIT -- every tile generates its rays and runs its tests, "
                              "also the tiles whose winner is certain for the whole ray family (identical image)"}
+    emitted = threading.Lock()
+    state = {"done": False}
+
+    def emit(c5):
+        """The one JSON line (rank 0).  A function so that the watchdog of the extra N > 1 record can still print the headline."""
+        with emitted:
+            if state["done"]:
+                return
+            state["done"] = True
+            rays_band0 = cfg["width"] * band0_rows * cfg["samples"] * cfg["iterations"]
+            total_rays = cfg["width"] * cfg["height"] * (n_parts if weak else 1) * cfg["samples"] * cfg["iterations"]
+            value = total_rays * args.steps / elapsed / 1e6
+
+            if rank == 0:
+                avg_kernel_s = kernel_ms / max(launches, 1) / 1e3
+                b_alg = algorithmic_bytes(cfg["width"], band0_rows, n_tris, spheres.shape[0])        # one GPU's band
+                b_alg48 = algorithmic_bytes(cfg["width"], band0_rows, n_tris, spheres.shape[0], 48)
+                achieved = b_alg / avg_kernel_s / 1e9
+                step_s = elapsed / args.steps
+                traffic, traffic_stale = stamped(os.path.join(ROOT, "profiles", "hbm_traffic.json"), args.config, kernel_hash)
+                split = band0_rows >= 128 and os.environ.get("RT_MI355X_NO_SPLIT") != "1"
+                out = {
+                    "metric": "Mray/s at %dx%dx%dspp" % (cfg["width"], cfg["height"], cfg["samples"]),
+                    "value": round(value, 2), "unit": "Mray/s", "n_gpus": n_parts, "steps": args.steps,
+                    "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 5),
+                    "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32",
+                    "data": "synthetic",
+                    "clock_preheat": ({"ms": round(max(h[2] for h in heat.values()), 1), "clock_ghz": round(min(h[1] for h in heat.values()), 3),
+                                       "note": "before the W warmup steps every device ran the VALU calibration loop of the valu record for this long, so "
+                                               "that the timed steps run at the device's steady clocks (tools/clock_ramp.py: a cold device needs ~250 "
+                                               "steps = 25 ms of load to get there); no step of the path runs in it; --no-preheat turns it off"}
+                                      if heat else None),
+                    "config": {"workload": WORKLOADS[args.config],
+                               "image": "%dx%d per GPU (row band of a %dx%d frame)" % (
+                                   cfg["width"], band0_rows, cfg["width"], cfg["height"] * (n_parts if weak else 1)),
+                               "triangles": n_tris, "spheres": int(spheres.shape[0]), "samples_per_launch": cfg["samples"],
+                               "launch": launch_info, "math_mode": "fma", "rng_seed": cfg["seed"],
+                               "sharding": sharding, "library": version},
+                    "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(achieved / HBM_PEAK_GBS, 5),
+                                 "frac_wall": round(b_alg / step_s / 1e9 / HBM_PEAK_GBS, 5),
+                                 "traffic": traffic.get("bytes_per_launch") if traffic else None,
+                                 "kernel": "trace_kernel", "kernel_us": round(avg_kernel_s * 1e6, 2),
+                                 "kernels_per_launch": 2 if split else 1,
+                                 "kernel_Mray_s": round(rays_band0 / avg_kernel_s / 1e6, 2),
+                                 "algorithmic_bytes_per_launch": b_alg, "rng_state_bytes": RNG_STATE_BYTES,
+                                 "reference_layout_R48": {"algorithmic_bytes_per_launch": b_alg48,
+                                                          "frac": round(b_alg48 / avg_kernel_s / 1e9 / HBM_PEAK_GBS, 5),
+                                                          "note": "what the same kernel time would read with the reference's 48-byte curandState_t "
+                                                                  "accounting (SURVEY 8d); those bytes are NOT moved: the build persists 24 B/pixel"},
+                                 "note": "contractual bound; the path is fp32-VALU-issue-bound by construction (SURVEY.md 0.5, BASELINE.md 2): see "
+                                         "valu.  A launch runs as two half-frame kernels on two streams that execute concurrently "
+                                         "(profiles/r02_c3_overlap.csv): kernel_us is the sampled duration of one of them (what rocprofv3 lists per "
+                                         "dispatch), frac = the launch's algorithmic bytes / kernel_us / peak, frac_wall = the same bytes / "
+                                         "ms_per_step / peak (clear, both kernels, conversion, launch gaps: everything a step costs)"},
+                }
+                if traffic_stale:
+                    out["roofline"]["traffic_stale"] = True      # profiles/hbm_traffic.json belongs to another kernel build
+                if n_parts > 1:
+                    out["config"]["devices"] = [b["device"] for b in bands] if bands and len(bands) > 1 else list(range(n_parts))
+                    out["gather_ms"] = round(res["gather_ms"] / res["gathers"], 4) if res["gathers"] else 0.0
+                    out["gather_note"] = ("device time of one gather on the root's gather stream (HIP events around the grouped ncclSend/ncclRecv; "
+                                          "includes waiting for the slowest peer's tile); it overlaps the next step's tracing.  0 with every band "
+                                          "on the root device: those tiles are written in place by the trace kernel")
+                    if c5 is not None:
+                        out["c5_strong"] = c5
+                if warm is not None:
+                    out["warm_lists"] = warm
+                if full_path is not None:
+                    out["full_path_all_tiles"] = full_path
+                if not args.no_valu and n_parts == 1 and args.config != "C5":
+                    # instrumented launch of the reference's own algorithm (every ray scans the whole list,
+                    # reference-order tests) on a scratch tracer: exit points per test
+                    g = R.RayTracer((cfg["width"], cfg["height"]), (0, 0, 0), cfg["angles"], cfg["fov"], cfg["focal"],
+                                    cfg["aperture"], seed=cfg["seed"], device=local_rank, no_filter=True, no_binning=True)
+                    if tris.shape[0]:
+                        g.UploadScene(tris)
+                    if spheres.shape[0]:
+                        g.UploadSpheres(spheres)
+                    st_samples = cfg["samples"] if args.config != "C4" else 4
+                    st = g.TraceStats(st_samples)
+                    g.close()
+                    exits = [st["exit_det"], st["exit_u"], st["exit_v"], st["exit_hit"]]
+                    scale = cfg["samples"] / st_samples
+                    flop = scale * sum(f * e for f, e in zip(FLOP_BY_EXIT, exits)) + FLOP_PER_RAY_SETUP * rays_band0
+                    lane_fma, ghz = heat[local_rank][:2] if local_rank in heat else api.dbg_valu_peak(local_rank)
+                    rate_peak = lane_fma / 64.0                      # wave64 VALU instructions per second, whole device
+                    tf = flop / avg_kernel_s / 1e12
+                    issued, issued_stale = stamped(os.path.join(ROOT, "profiles", "valu_issue.json"), args.config, kernel_hash)
+                    valu = {"bound": "fp32 VALU issue", "unit": "Ginst/s (wave64)", "peak": round(rate_peak / 1e9, 2),
+                            "peak_note": "wave64 instruction rate of an 8-chain v_fma_f32 loop at 8 waves/SIMD on this device, measured now",
+                            "clock_ghz_under_load": round(ghz, 3), "achieved": None, "frac": None}
+                    if issued:
+                        n_inst = issued["valu_wave_instructions_per_launch"]
+                        valu.update({"achieved": round(n_inst / avg_kernel_s / 1e9, 2), "frac": round(n_inst / avg_kernel_s / rate_peak, 4),
+                                     "valu_wave_instructions_per_launch": n_inst,
+                                     "lane_instructions_per_ray": round(n_inst * 64.0 / rays_band0, 1),
+                                     "note": "SQ_INSTS_VALU per launch (rocprofv3 --pmc, own pass, same kernel build) / kernel time"})
+                    elif issued_stale:
+                        valu["stale"] = True                         # profiles/valu_issue.json belongs to another kernel build
+                    valu["algorithmic"] = {
+                        "full_scan_tflops_equivalent": round(tf, 2), "spec_peak_tflops": VALU_PEAK_TFLOPS,
+                        "ratio_to_spec_peak": round(tf / VALU_PEAK_TFLOPS, 4),
+                        "tests_per_s": round(scale * sum(exits) / avg_kernel_s, 1),
+                        "exit_fractions": [round(e / max(sum(exits), 1), 4) for e in exits],
+                        "algorithmic_flop_per_launch": int(flop),
+                        "note": "NOT a utilisation: the flops of the reference's full scan (every ray x every triangle priced by its exit point, "
+                                "20/30/46/52, FMA = 2, + 100 per ray) divided by this kernel's time.  The kernel skips the triangles its per-tile "
+                                "classification proves missed, so the ratio may exceed 1"}
+                    g = R.RayTracer((cfg["width"], cfg["height"]), (0, 0, 0), cfg["angles"], cfg["fov"], cfg["focal"],
+                                    cfg["aperture"], seed=cfg["seed"], device=local_rank)
+                    if tris.shape[0]:
+                        g.UploadScene(tris)
+                    sb = g.TraceStats(st_samples)
+                    g.close()
+                    waves = ((cfg["width"] + 7) // 8) * ((cfg["height"] + 7) // 8)
+                    valu["binning"] = {"candidates_per_tile": round(sb["bin_candidates"] / max(sb["bin_rounds"], 1), 2),
+                                       "of_triangles": n_tris, "classification_rounds_per_tile": round(sb["bin_rounds"] / waves, 3)}
+                    tl = sb.get("tiles_by_list", {})
+                    if sum(tl.values()):
+                        valu["binning"]["tiles"] = {k: round(v / sum(tl.values()), 4) for k, v in tl.items()}
+                        valu["binning"]["tiles_note"] = ("share of the 8x8 tiles with a CERTAIN winner (one triangle every ray of the tile's family certainly hits "
+                                                         "and that is certainly the farthest hit: their samples keep only the RNG draws and the additions), and of "
+                                                         "the others by the length of their candidate list")
+                    out["valu"] = valu
+                if n_parts == 1 and args.cpu_rows != 0:
+                    rows = args.cpu_rows if args.cpu_rows > 0 else min(cfg["height"], {"C2": 512, "C3": 1080, "C4": 8, "C5": 2}[args.config])
+                    out["cpu_baseline"] = cpu_baseline(cfg, tris, spheres, rows, host_threads())
+                print(json.dumps(out), flush=True)
+
     # N > 1: the strong-scaling record of BASELINE configs[4] beside the weak headline
     c5 = None
+    watchdog = None
+    if n_parts > 1:
+        # Everything from here on is extra (the headline is measured): a rank that blocks in it -- a collective whose peer
+        # died, a communicator that does not form -- must not cost the run its line.  After RT_MI355X_C5_TIMEOUT seconds
+        # rank 0 prints the headline with the reason in c5_strong and every rank leaves.
+        limit = float(os.environ.get("RT_MI355X_C5_TIMEOUT", "300"))
+
+        def give_up():
+            if rank == 0:
+                emit({"workload": WORKLOADS["C5"], "error": "the extra record or the final barrier did not finish within %.0f s" % limit})
+            sys.stdout.flush()
+            os._exit(0)
+
+        watchdog = threading.Timer(limit, give_up)
+        watchdog.daemon = True
+        watchdog.start()
     if n_parts > 1 and args.config == "C3" and not args.no_c5:
         try:
             cfg5 = dict(scenes.CONFIGS["C5"])
@@ -323,126 +472,10 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
 
-    rays_band0 = cfg["width"] * band0_rows * cfg["samples"] * cfg["iterations"]
-    total_rays = cfg["width"] * cfg["height"] * (n_parts if weak else 1) * cfg["samples"] * cfg["iterations"]
-    value = total_rays * args.steps / elapsed / 1e6
-
+    if watchdog is not None:
+        watchdog.cancel()
     if rank == 0:
-        avg_kernel_s = kernel_ms / max(launches, 1) / 1e3
-        b_alg = algorithmic_bytes(cfg["width"], band0_rows, n_tris, spheres.shape[0])        # one GPU's band
-        b_alg48 = algorithmic_bytes(cfg["width"], band0_rows, n_tris, spheres.shape[0], 48)
-        achieved = b_alg / avg_kernel_s / 1e9
-        step_s = elapsed / args.steps
-        traffic, traffic_stale = stamped(os.path.join(ROOT, "profiles", "hbm_traffic.json"), args.config, kernel_hash)
-        split = band0_rows >= 128 and os.environ.get("RT_MI355X_NO_SPLIT") != "1"
-        out = {
-            "metric": "Mray/s at %dx%dx%dspp" % (cfg["width"], cfg["height"], cfg["samples"]),
-            "value": round(value, 2), "unit": "Mray/s", "n_gpus": n_parts, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 5),
-            "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "clock_preheat": ({"ms": round(max(h[2] for h in heat.values()), 1), "clock_ghz": round(min(h[1] for h in heat.values()), 3),
-                               "note": "before the W warmup steps every device ran the VALU calibration loop of the valu record for this long, so "
-                                       "that the timed steps run at the device's steady clocks (tools/clock_ramp.py: a cold device needs ~250 "
-                                       "steps = 25 ms of load to get there); no step of the path runs in it; --no-preheat turns it off"}
-                              if heat else None),
-            "config": {"workload": WORKLOADS[args.config],
-                       "image": "%dx%d per GPU (row band of a %dx%d frame)" % (
-                           cfg["width"], band0_rows, cfg["width"], cfg["height"] * (n_parts if weak else 1)),
-                       "triangles": n_tris, "spheres": int(spheres.shape[0]), "samples_per_launch": cfg["samples"],
-                       "launch": launch_info, "math_mode": "fma", "rng_seed": cfg["seed"],
-                       "sharding": sharding, "library": version},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "frac_wall": round(b_alg / step_s / 1e9 / HBM_PEAK_GBS, 5),
-                         "traffic": traffic.get("bytes_per_launch") if traffic else None,
-                         "kernel": "trace_kernel", "kernel_us": round(avg_kernel_s * 1e6, 2),
-                         "kernels_per_launch": 2 if split else 1,
-                         "kernel_Mray_s": round(rays_band0 / avg_kernel_s / 1e6, 2),
-                         "algorithmic_bytes_per_launch": b_alg, "rng_state_bytes": RNG_STATE_BYTES,
-                         "reference_layout_R48": {"algorithmic_bytes_per_launch": b_alg48,
-                                                  "frac": round(b_alg48 / avg_kernel_s / 1e9 / HBM_PEAK_GBS, 5),
-                                                  "note": "what the same kernel time would read with the reference's 48-byte curandState_t "
-                                                          "accounting (SURVEY 8d); those bytes are NOT moved: the build persists 24 B/pixel"},
-                         "note": "contractual bound; the path is fp32-VALU-issue-bound by construction (SURVEY.md 0.5, BASELINE.md 2): see "
-                                 "valu.  A launch runs as two half-frame kernels on two streams that execute concurrently "
-                                 "(profiles/r02_c3_overlap.csv): kernel_us is the sampled duration of one of them (what rocprofv3 lists per "
-                                 "dispatch), frac = the launch's algorithmic bytes / kernel_us / peak, frac_wall = the same bytes / "
-                                 "ms_per_step / peak (clear, both kernels, conversion, launch gaps: everything a step costs)"},
-        }
-        if traffic_stale:
-            out["roofline"]["traffic_stale"] = True      # profiles/hbm_traffic.json belongs to another kernel build
-        if n_parts > 1:
-            out["config"]["devices"] = [b["device"] for b in bands] if bands and len(bands) > 1 else list(range(n_parts))
-            out["gather_ms"] = round(res["gather_ms"] / res["gathers"], 4) if res["gathers"] else 0.0
-            out["gather_note"] = ("device time of one gather on the root's gather stream (HIP events around the grouped ncclSend/ncclRecv; "
-                                  "includes waiting for the slowest peer's tile); it overlaps the next step's tracing.  0 with every band "
-                                  "on the root device: those tiles are written in place by the trace kernel")
-            if c5 is not None:
-                out["c5_strong"] = c5
-        if warm is not None:
-            out["warm_lists"] = warm
-        if full_path is not None:
-            out["full_path_all_tiles"] = full_path
-        if not args.no_valu and n_parts == 1 and args.config != "C5":
-            # instrumented launch of the reference's own algorithm (every ray scans the whole list,
-            # reference-order tests) on a scratch tracer: exit points per test
-            g = R.RayTracer((cfg["width"], cfg["height"]), (0, 0, 0), cfg["angles"], cfg["fov"], cfg["focal"],
-                            cfg["aperture"], seed=cfg["seed"], device=local_rank, no_filter=True, no_binning=True)
-            if tris.shape[0]:
-                g.UploadScene(tris)
-            if spheres.shape[0]:
-                g.UploadSpheres(spheres)
-            st_samples = cfg["samples"] if args.config != "C4" else 4
-            st = g.TraceStats(st_samples)
-            g.close()
-            exits = [st["exit_det"], st["exit_u"], st["exit_v"], st["exit_hit"]]
-            scale = cfg["samples"] / st_samples
-            flop = scale * sum(f * e for f, e in zip(FLOP_BY_EXIT, exits)) + FLOP_PER_RAY_SETUP * rays_band0
-            lane_fma, ghz = heat[local_rank][:2] if local_rank in heat else api.dbg_valu_peak(local_rank)
-            rate_peak = lane_fma / 64.0                      # wave64 VALU instructions per second, whole device
-            tf = flop / avg_kernel_s / 1e12
-            issued, issued_stale = stamped(os.path.join(ROOT, "profiles", "valu_issue.json"), args.config, kernel_hash)
-            valu = {"bound": "fp32 VALU issue", "unit": "Ginst/s (wave64)", "peak": round(rate_peak / 1e9, 2),
-                    "peak_note": "wave64 instruction rate of an 8-chain v_fma_f32 loop at 8 waves/SIMD on this device, measured now",
-                    "clock_ghz_under_load": round(ghz, 3), "achieved": None, "frac": None}
-            if issued:
-                n_inst = issued["valu_wave_instructions_per_launch"]
-                valu.update({"achieved": round(n_inst / avg_kernel_s / 1e9, 2), "frac": round(n_inst / avg_kernel_s / rate_peak, 4),
-                             "valu_wave_instructions_per_launch": n_inst,
-                             "lane_instructions_per_ray": round(n_inst * 64.0 / rays_band0, 1),
-                             "note": "SQ_INSTS_VALU per launch (rocprofv3 --pmc, own pass, same kernel build) / kernel time"})
-            elif issued_stale:
-                valu["stale"] = True                         # profiles/valu_issue.json belongs to another kernel build
-            valu["algorithmic"] = {
-                "full_scan_tflops_equivalent": round(tf, 2), "spec_peak_tflops": VALU_PEAK_TFLOPS,
-                "ratio_to_spec_peak": round(tf / VALU_PEAK_TFLOPS, 4),
-                "tests_per_s": round(scale * sum(exits) / avg_kernel_s, 1),
-                "exit_fractions": [round(e / max(sum(exits), 1), 4) for e in exits],
-                "algorithmic_flop_per_launch": int(flop),
-                "note": "NOT a utilisation: the flops of the reference's full scan (every ray x every triangle priced by its exit point, "
-                        "20/30/46/52, FMA = 2, + 100 per ray) divided by this kernel's time.  The kernel skips the triangles its per-tile "
-                        "classification proves missed, so the ratio may exceed 1"}
-            g = R.RayTracer((cfg["width"], cfg["height"]), (0, 0, 0), cfg["angles"], cfg["fov"], cfg["focal"],
-                            cfg["aperture"], seed=cfg["seed"], device=local_rank)
-            if tris.shape[0]:
-                g.UploadScene(tris)
-            sb = g.TraceStats(st_samples)
-            g.close()
-            waves = ((cfg["width"] + 7) // 8) * ((cfg["height"] + 7) // 8)
-            valu["binning"] = {"candidates_per_tile": round(sb["bin_candidates"] / max(sb["bin_rounds"], 1), 2),
-                               "of_triangles": n_tris, "classification_rounds_per_tile": round(sb["bin_rounds"] / waves, 3)}
-            tl = sb.get("tiles_by_list", {})
-            if sum(tl.values()):
-                valu["binning"]["tiles"] = {k: round(v / sum(tl.values()), 4) for k, v in tl.items()}
-                valu["binning"]["tiles_note"] = ("share of the 8x8 tiles with a CERTAIN winner (one triangle every ray of the tile's family certainly hits "
-                                                 "and that is certainly the farthest hit: their samples keep only the RNG draws and the additions), and of "
-                                                 "the others by the length of their candidate list")
-            out["valu"] = valu
-        if n_parts == 1 and args.cpu_rows != 0:
-            rows = args.cpu_rows if args.cpu_rows > 0 else min(cfg["height"], {"C2": 512, "C3": 1080, "C4": 8, "C5": 2}[args.config])
-            out["cpu_baseline"] = cpu_baseline(cfg, tris, spheres, rows, host_threads())
-        print(json.dumps(out), flush=True)
+        emit(c5)
 
 
 if __name__ == "__main__":
