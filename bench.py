@@ -31,6 +31,8 @@ Prints ONE JSON line on rank 0 with
   gather_ms     N > 1: device time of one tile gather on the root's gather stream
   c5_strong     N > 1: the strong-scaling record; measured after the headline under a watchdog (RT_MI355X_C5_TIMEOUT, 300 s):
                 if it or the final barrier blocks, rank 0 still prints the line, with the reason in c5_strong.error
+                (a sharded run that makes no progress before the headline is measured ends after RT_MI355X_BENCH_TIMEOUT,
+                900 s, with value null and the phase it was in)
   warm_lists    NOT the headline: the same steps with the library's default list reuse across Traces
   full_path_all_tiles  NOT the headline: the same steps with certain-winner tiles switched off (every tile traces its rays)
   cpu_baseline  the oracle (scalar CPU port of the reference kernel) timed on this box's cores, N = 1 only
@@ -223,6 +225,23 @@ def main():
     n_tris = tris.shape[0] // 3
     weak = args.config != "C5"
 
+    # A sharded run that blocks for good (a collective whose peer never arrives) ends with a reason instead of the
+    # launcher's kill: after RT_MI355X_BENCH_TIMEOUT seconds rank 0 says in which phase, every rank leaves.
+    phase = {"name": "setting up the job"}
+    if n_parts > 1:
+        def stuck():
+            if phase["name"] is None:
+                return
+            sys.stderr.write("bench.py rank %d: no progress while %s\n" % (rank, phase["name"]))
+            if rank == 0:
+                print(json.dumps({"metric": "Mray/s at %dx%dx%dspp" % (cfg["width"], cfg["height"], cfg["samples"]), "value": None,
+                                  "unit": "Mray/s", "n_gpus": n_parts, "error": "timed out while %s" % phase["name"]}), flush=True)
+            sys.stderr.flush()
+            os._exit(3)
+
+        whole = threading.Timer(float(os.environ.get("RT_MI355X_BENCH_TIMEOUT", "900")), stuck)
+        whole.daemon = True
+        whole.start()
     try:
         job = RowBandJob(cfg, tris, spheres, world=world, rank=rank, local_rank=local_rank, weak=weak, devices=devices,
                          samples_in_flight=args.samples_in_flight, lds_chunk=args.lds_chunk)
@@ -238,8 +257,10 @@ def main():
     # Headline: every step is a from-scratch Trace pass -- the tile candidate lists (a camera-dependent
     # acceleration structure the library keeps between Traces by default) are NOT carried from step to step.
     job.tracer.SetListReuse(False)
+    phase["name"] = "measuring the headline steps"
     heat = {} if args.no_preheat else preheat(devices if devices else [local_rank])
     res = timed_steps(job, args.steps, args.warmup)
+    phase["name"] = None                                   # the headline is in hand: from here on emit() is the way out
     elapsed, kernel_ms, launches = res["elapsed"], res["kernel_ms"], res["launches"]
     bands = job.tracer.Bands()
     band0_rows = bands[0]["rows"]
@@ -266,32 +287,8 @@ def main():
     launch_info = job.tracer.Info()
     version = R.load_library().rt_version().decode()
     kernel_hash = version.split("kernels=")[-1].rstrip(")") if "kernels=" in version else None
-    job.close(destroy_group=False)
-
     full_path = None
-    if n_parts == 1 and args.config in ("C3",) and not args.no_warm:
-        # the same cold steps with every tile on the full path (RT_FLAG_NO_SURE_HIT: tiles with a certain winner generate their
-        # rays and run their tests anyway) -- what the kernel does per ray when nothing can be proven, next to the headline
-        fp = R.RayTracer((cfg["width"], cfg["height"]), (0.0, 0.0, 0.0), cfg["angles"], cfg["fov"], cfg["focal"], cfg["aperture"],
-                         seed=cfg["seed"], device=local_rank, no_sure_hit=True)
-        if tris.shape[0]:
-            fp.UploadScene(tris)
-        fp.SetListReuse(False)
-        for _ in range(max(args.warmup, 2)):
-            fp.TraceEnqueue(cfg["iterations"], cfg["samples"])
-        fp.Sync()
-        fp.KernelTime(reset=True)
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            fp.TraceEnqueue(cfg["iterations"], cfg["samples"])
-        fp.Sync()
-        dt = time.perf_counter() - t1
-        fk_ms, fk_n = fp.KernelTime(reset=True)
-        fp.close()
-        full_path = {"value": round(cfg["width"] * cfg["height"] * cfg["samples"] * cfg["iterations"] * args.steps / dt / 1e6, 2), "unit": "Mray/s",
-                     "ms_per_step": round(dt / args.steps * 1e3, 5), "kernel_us": round(fk_ms / max(fk_n, 1) * 1e3, 2),
-                     "note": "NOT the headline: the same steps with RT_FLAG_NO_SURE_HIT -- every tile generates its rays and runs its tests, "
-                             "also the tiles whose winner is certain for the whole ray family (identical image)"}
+    c5 = None
     emitted = threading.Lock()
     state = {"done": False}
 
@@ -422,8 +419,6 @@ def main():
                     out["cpu_baseline"] = cpu_baseline(cfg, tris, spheres, rows, host_threads())
                 print(json.dumps(out), flush=True)
 
-    # N > 1: the strong-scaling record of BASELINE configs[4] beside the weak headline
-    c5 = None
     watchdog = None
     if n_parts > 1:
         # Everything from here on is extra (the headline is measured): a rank that blocks in it -- a collective whose peer
@@ -440,6 +435,32 @@ def main():
         watchdog = threading.Timer(limit, give_up)
         watchdog.daemon = True
         watchdog.start()
+    job.close(destroy_group=False)
+
+    if n_parts == 1 and args.config in ("C3",) and not args.no_warm:
+        # the same cold steps with every tile on the full path (RT_FLAG_NO_SURE_HIT: tiles with a certain winner generate their
+        # rays and run their tests anyway) -- what the kernel does per ray when nothing can be proven, next to the headline
+        fp = R.RayTracer((cfg["width"], cfg["height"]), (0.0, 0.0, 0.0), cfg["angles"], cfg["fov"], cfg["focal"], cfg["aperture"],
+                         seed=cfg["seed"], device=local_rank, no_sure_hit=True)
+        if tris.shape[0]:
+            fp.UploadScene(tris)
+        fp.SetListReuse(False)
+        for _ in range(max(args.warmup, 2)):
+            fp.TraceEnqueue(cfg["iterations"], cfg["samples"])
+        fp.Sync()
+        fp.KernelTime(reset=True)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            fp.TraceEnqueue(cfg["iterations"], cfg["samples"])
+        fp.Sync()
+        dt = time.perf_counter() - t1
+        fk_ms, fk_n = fp.KernelTime(reset=True)
+        fp.close()
+        full_path = {"value": round(cfg["width"] * cfg["height"] * cfg["samples"] * cfg["iterations"] * args.steps / dt / 1e6, 2), "unit": "Mray/s",
+                     "ms_per_step": round(dt / args.steps * 1e3, 5), "kernel_us": round(fk_ms / max(fk_n, 1) * 1e3, 2),
+                     "note": "NOT the headline: the same steps with RT_FLAG_NO_SURE_HIT -- every tile generates its rays and runs its tests, "
+                             "also the tiles whose winner is certain for the whole ray family (identical image)"}
+    # N > 1: the strong-scaling record of BASELINE configs[4] beside the weak headline
     if n_parts > 1 and args.config == "C3" and not args.no_c5:
         try:
             cfg5 = dict(scenes.CONFIGS["C5"])
