@@ -292,6 +292,20 @@ int rt_dbg_read_tile_lists(rt_tracer* t, uint32_t* dst, size_t capacity_words, u
  * focal: 3 floats per pixel.  curv_scale multiplies the curvature term for THIS launch only (1 = product; the test's
  * teeth: with 0 some pixel's focal point must fall outside its box). */
 int rt_dbg_focal_boxes(rt_tracer* t, float curv_scale, float* boxes, size_t boxes_capacity, float* focal, size_t focal_capacity);
+/* The conservative classification verdict by verdict (tests/test_gpu_classification.py, CLASSIFICATION.md): for each of
+ * n_regions regions of the band -- level 0: the 8x8 wave tile at pixel (regions[2i], regions[2i+1]) (x a multiple of 8, band-local
+ * row a multiple of 8), bounded exactly as a trace wave bounds it; level 1: the 32x8 block (x a multiple of 32), the union of
+ * its four wave tiles; level 2: the 128x64 macro tile -- and for EVERY triangle of the scene, what tile_misses_triangle decides
+ * and the interval ends it decides from, with every rounding allowance multiplied by slack_milli / 1000 (1000 = the product;
+ * 300, 100, 30, 10, 0 exist so that the margin can be measured in the shipped library).
+ *   out[region] = 16 floats: focal box lo[3], hi[3], lmin, lmax of |F - o|, usable, lens radius A, orad[3], fc[3], followed by
+ *   n_tris records.  forms == 0 (small-scene instantiation), 12 floats: flags (1 = kept, 2 = certainly hit by every ray of the
+ *   family), det_lo, det_hi, U_lo, U_hi, V_lo, V_hi (bounds of det', U', V' = the reference's det, U = dot(tv, pv), V = dot(dir, qv)
+ *   of Kernels.cuh:40,50,57 times |F - o|), q_lo, q_hi (bounds of t / |F - o|, t of Kernels.cuh:63), Nt_lo, Nt_hi, 0.
+ *   forms != 0 (large-scene instantiation with the per-sample forms), 32 floats: flags (1 = kept), the six ends, 5 x 0, then the
+ *   forms {F1.c0, cx, cy, F2..., F3..., g1.xyz, g2.xyz, g3.xyz} with the gradients as the bf16 values the kernel stores, 2 x 0. */
+int rt_dbg_classify(rt_tracer* t, uint32_t level, uint32_t forms, uint32_t slack_milli, const uint32_t* regions, uint32_t n_regions,
+                    float* out, size_t capacity_floats);
 /* states n*6 {d,v0..v4} advanced in place, out n*m uniforms in (0,1] */
 int rt_dbg_uniform(int device, uint32_t n, uint32_t m, uint32_t* states, float* out);
 /* thin-lens rays of the tracer's current camera for n (x, y) pixels with given RNG states */

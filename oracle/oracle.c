@@ -327,6 +327,21 @@ void orc_radiance(const orc_scene* sc, const float ray[6], int contract, float r
   st3(rgb, contract ? radiance_fma(sc, ld_ray(ray)) : radiance_strict(sc, ld_ray(ray)));
 }
 
+void orc_probe_init(orc_probe_tri* out, uint32_t n_tris) {
+  for (uint32_t i = 0; i < n_tris; ++i) {
+    memset(out + i, 0, sizeof out[i]);
+    out[i].det_min = out[i].U_min = out[i].V_min = out[i].q_min = INFINITY;
+    out[i].det_max = out[i].U_max = out[i].V_max = out[i].q_max = -INFINITY;
+  }
+}
+
+void orc_tile_probe(const orc_scene* sc, const orc_camera* cam, uint32_t W, uint32_t H, const uint32_t* pixels,
+                    uint32_t n_pixels, const float* lens, uint32_t n_lens, int contract, const float* forms,
+                    const float* fc, orc_probe_tri* out, uint32_t* no_hit_rays) {
+  if (contract) tile_probe_fma(sc, cam, W, H, pixels, n_pixels, lens, n_lens, forms, fc, out, no_hit_rays);
+  else tile_probe_strict(sc, cam, W, H, pixels, n_pixels, lens, n_lens, forms, fc, out, no_hit_rays);
+}
+
 /* =====================================================================================
  * Frame-level: RNG state creation, clear, one TraceKernel launch, conversion
  * ===================================================================================== */

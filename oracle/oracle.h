@@ -119,6 +119,20 @@ typedef struct orc_frame {
   uint32_t* image;
 } orc_frame;
 
+/* Probe of a ray family (test infrastructure of the product's conservative classification): the reference's HitTriangle
+ * arithmetic (Kernels.cuh:39-63) and farthest-hit scan (:73-92) for the rays of n_pixels pixels x n_lens lens samples
+ * (unit-disk points as Random.cuh:13-19 returns them; rays built as ThinLensCamera.cuh:41-51) against every triangle.
+ * out[n_tris] must be initialised with orc_probe_init; several calls accumulate. */
+typedef struct orc_probe_tri {
+  uint32_t rays, hits, wins, nan_hits;      /* rays probed; HitTriangle returned true; Radiance's winner; hits with t = NaN */
+  uint32_t nan_rays, form_rejects, form_wrong, pad;   /* rays whose det, U or V is NaN; rays the per-sample forms skip; of those, hit */
+  double det_min, det_max, U_min, U_max, V_min, V_max;   /* over the rays: det |w|, U |w|, V |w| (w = focal point - lens point) */
+  double q_min, q_max;                      /* over the hit rays: t / |w| */
+} orc_probe_tri;
+void orc_probe_init(orc_probe_tri* out, uint32_t n_tris);
+void orc_tile_probe(const orc_scene* sc, const orc_camera* cam, uint32_t W, uint32_t H, const uint32_t* pixels,
+                    uint32_t n_pixels, const float* lens, uint32_t n_lens, int contract, const float* forms,
+                    const float* fc, orc_probe_tri* out, uint32_t* no_hit_rays);
 void orc_radiance(const orc_scene* sc, const float ray[6], int contract, float rgb[3]);
 void orc_normalize(const float v[3], int contract, float out[3]);        /* glm::normalize */
 void orc_frame_rng_init(orc_frame* f, uint64_t seed, int nthreads);      /* Random.cu:10-52   */

@@ -43,6 +43,12 @@ class Frame(C.Structure):
                 ("rng", C.POINTER(C.c_uint32)), ("image", C.POINTER(C.c_uint32))]
 
 
+# orc_probe_tri (oracle.h)
+PROBE_DTYPE = np.dtype([("rays", np.uint32), ("hits", np.uint32), ("wins", np.uint32), ("nan_hits", np.uint32),
+                        ("nan_rays", np.uint32), ("form_rejects", np.uint32), ("form_wrong", np.uint32), ("pad", np.uint32),
+                        ("det_min", np.float64), ("det_max", np.float64), ("U_min", np.float64), ("U_max", np.float64),
+                        ("V_min", np.float64), ("V_max", np.float64), ("q_min", np.float64), ("q_max", np.float64)])
+
 _lib = None
 
 
@@ -87,6 +93,11 @@ def lib():
         L.orc_convert.argtypes = [C.POINTER(Frame)]
         L.orc_pack_color.argtypes = [C.c_float, C.c_float, C.c_float]
         L.orc_pack_color.restype = C.c_uint32
+        L.orc_probe_init.argtypes = [C.c_void_p, C.c_uint32]
+        L.orc_probe_init.restype = None
+        L.orc_tile_probe.argtypes = [C.POINTER(Scene), C.POINTER(Camera), C.c_uint32, C.c_uint32, u32p, C.c_uint32, f32p,
+                                     C.c_uint32, C.c_int, f32p, f32p, C.c_void_p, u32p]
+        L.orc_tile_probe.restype = None
         _lib = L
     return _lib
 
@@ -129,6 +140,13 @@ def rng_next(state):
 
 def rng_uniform(state):
     return np.float32(lib().orc_rng_uniform(_up(state)))
+
+
+def uniform_on_disk(state):
+    """random::UnifromOnDisk (Random.cuh:13-19) from the state {d, v0..v4}, advanced in place (three draws)."""
+    xy = np.zeros(2, np.float32)
+    lib().orc_uniform_on_disk(_up(state), _fp(xy))
+    return xy
 
 
 def sincos(x):
@@ -261,6 +279,24 @@ class OracleTracer:
     def _scene(self):
         return Scene(_fp(self.tris), self.tris.shape[0], _fp(self.spheres), self.spheres.shape[0], self.hit_mode,
                      self.layout, self.shade_mode)
+
+    def tile_probe(self, pixels, lens, forms=None, fc=None):
+        """orc_tile_probe for the rays of `pixels` [(x, y of the full frame)] x `lens` [(dx, dy) in the unit disk] against every
+        triangle: (per-triangle structured array PROBE_DTYPE, rays that hit nothing)."""
+        pix = np.ascontiguousarray(pixels, np.uint32).reshape(-1, 2)
+        ln = np.ascontiguousarray(lens, np.float32).reshape(-1, 2)
+        out = np.zeros(self.tris.shape[0], PROBE_DTYPE)
+        L = lib()
+        L.orc_probe_init(out.ctypes.data, out.shape[0])
+        nohit = C.c_uint32(0)
+        sc = self._scene()
+        fo = None if forms is None else np.ascontiguousarray(forms, np.float32).reshape(-1, 18)
+        fcv = None if fc is None else np.ascontiguousarray(fc, np.float32).reshape(3)
+        assert fo is None or (fo.shape[0] == out.shape[0] and fcv is not None)
+        L.orc_tile_probe(C.byref(sc), C.byref(self.cam), self.W, self.H, _up(pix), pix.shape[0], _fp(ln), ln.shape[0],
+                         self.contract, None if fo is None else _fp(fo), None if fcv is None else _fp(fcv),
+                         out.ctypes.data, C.byref(nohit))
+        return out, int(nohit.value)
 
     def launch(self, samples):
         sc = self._scene()

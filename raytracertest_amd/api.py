@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "rt_dbg_rng_init_host",
     "rt_tracer_create_multi", "rt_group_unique_id", "rt_tracer_join_group", "rt_tracer_leave_group",
     "rt_tracer_gather_time", "rt_tracer_band_count", "rt_tracer_band_info",
-    "rt_tracer_join_group_bands", "rt_balance_rows", "rt_tracer_rebalance", "rt_tracer_set_band", "rt_dbg_read_tile_lists", "rt_dbg_focal_boxes",
+    "rt_tracer_join_group_bands", "rt_balance_rows", "rt_tracer_rebalance", "rt_tracer_set_band", "rt_dbg_read_tile_lists", "rt_dbg_focal_boxes", "rt_dbg_classify",
 ]
 
 
@@ -181,6 +181,7 @@ def load_library():
         L.rt_tracer_set_band.argtypes = [vp, C.c_uint32, C.c_uint32]
         L.rt_dbg_read_tile_lists.argtypes = [vp, u32p, C.c_size_t, u32p]
         L.rt_dbg_focal_boxes.argtypes = [vp, C.c_float, f32p, C.c_size_t, f32p, C.c_size_t]
+        L.rt_dbg_classify.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, u32p, C.c_uint32, f32p, C.c_size_t]
         _lib = L
         return _lib
 
@@ -456,6 +457,16 @@ class RayTracer:
         words = buf[:bx * by * 4 * w].reshape(by, bx * 4, w)[:, :, 0]
         return (words & 0x3FF).astype(np.int32), ((words >> 10) & 0x3FF).astype(np.int32), (words >> 31).astype(bool)
 
+    def DebugTileListWords(self):
+        """(tiles_y, tiles_x, 1 + bin_list) words of the stored tile lists: word 0 = count | winner << 10 | certain << 31, then
+        the kept triangle indices in ascending order (rt_dbg_read_tile_lists)."""
+        bx, by = (self.width + 31) // 32, (self.rows + 7) // 8
+        wpt = np.zeros(1, np.uint32)
+        buf = np.zeros(bx * (by + 1) * 4 * 1025, np.uint32)
+        self._check(self._lib.rt_dbg_read_tile_lists(self._h, _u32p(buf), buf.size, _u32p(wpt)))
+        w = int(wpt[0])
+        return buf[:bx * by * 4 * w].reshape(by, bx * 4, w).copy()
+
     def DebugFocalBoxes(self, curv_scale=1.0):
         """(boxes (tiles_y, tiles_x, 8): lo[3], hi[3], corner path, usable; focal (rows, width, 3)) of a trace launch's tiles."""
         bx, by = (self.width + 31) // 32, (self.rows + 7) // 8
@@ -463,6 +474,15 @@ class RayTracer:
         focal = np.zeros((self.rows, self.width, 3), np.float32)
         self._check(self._lib.rt_dbg_focal_boxes(self._h, float(curv_scale), _f32p(boxes), boxes.size, _f32p(focal), focal.size))
         return boxes, focal
+
+    def DebugClassify(self, regions, level=0, forms=False, slack_milli=1000):
+        """rt_dbg_classify: (header (n, 16), records (n, n_tris, 12 | 32)) for the regions [(x0, y0)] of the band."""
+        reg = np.ascontiguousarray(regions, np.uint32).reshape(-1, 2)
+        n_tris = self.Info()["n_tris"]
+        per = 16 + n_tris * (32 if forms else 12)
+        out = np.zeros((reg.shape[0], per), np.float32)
+        self._check(self._lib.rt_dbg_classify(self._h, level, 1 if forms else 0, slack_milli, _u32p(reg), reg.shape[0], _f32p(out), out.size))
+        return out[:, :16], out[:, 16:].reshape(reg.shape[0], n_tris, 32 if forms else 12)
 
     def DebugGetRay(self, pixels, states):
         pix = np.ascontiguousarray(pixels, np.uint32).reshape(-1, 2)

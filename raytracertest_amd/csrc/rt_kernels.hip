@@ -153,6 +153,85 @@ __global__ __launch_bounds__(256) void dbg_focal_boxes_kernel(const TraceParams 
   }
 }
 
+// ------------------------------------------------------------------------------------
+// The conservative classification, verdict by verdict (harness of tests/test_gpu_classification.py).
+// One block per REGION of the band -- level 0: the 8x8 wave tile at (x0, y0), bounded exactly as a trace wave bounds
+// it (focal_bounds: corner path for full tiles); level 1: the 32x8 block at (x0, y0), the union of its four wave tiles
+// (block_focal_union, the trace kernel's block-level pre-cull); level 2: the macro tile of p.macro_w x p.macro_h pixels
+// at (x0, y0) (macro_focal_bounds, macro_bin_kernel) -- and for EVERY triangle of the scene what
+// tile_misses_triangle decides and the interval ends it decides from, with every rounding allowance scaled by SL::scale.
+//   out[region] = 16 header floats: focal lo[3], hi[3], lmin, lmax, usable, A, orad[3], fc[3]
+//               + n_tris x stride floats: flags (1 keep | 2 certainly hit), det_lo, det_hi, U_lo, U_hi, V_lo, V_hi,
+//                 q_lo, q_hi, Nt_lo, Nt_hi, 0 (stride 12; the small-scene instantiation <false, SURE>), or, FORMS:
+//                 flags (1 keep), the same six ends, 5 x 0, then the 18 numbers of the per-sample forms with the gradients
+//                 [9..17] rounded to bf16 as the trace kernel stores them (stride 32; the large-scene instantiation).
+// ------------------------------------------------------------------------------------
+template <bool FMA, bool FORMS, class SL>
+__global__ __launch_bounds__(256) void dbg_classify_kernel(const TraceParams p, uint32_t level, const uint32_t* __restrict__ regions,
+                                                            float* __restrict__ out) {
+  __shared__ float s_box[4][8];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t x0 = regions[2u * blockIdx.x], y0 = regions[2u * blockIdx.x + 1u];
+  constexpr uint32_t stride = FORMS ? 32u : 12u;
+  float* const o = out + static_cast<size_t>(blockIdx.x) * (16u + static_cast<size_t>(p.n_tris) * stride);
+  FocalBounds bb;
+  if (level == 2u) {
+    bb = macro_focal_bounds<FMA>(p, x0, y0, s_box);
+  } else {
+    const uint32_t px = x0 + wave * 8u + (lane & 7u), ly = y0 + (lane >> 3);
+    const bool inside = px < p.W && ly < p.rows;
+    const uint32_t cxp = inside ? px : 0u, cyp = inside ? ly : 0u;
+    V3 po, pd;
+    pinhole<FMA>(p, cxp, p.row0 + cyp, po, pd);
+    const FocalBounds wb = focal_bounds<SL>(p, focal_point<FMA>(p, pd), inside);
+    const FocalBounds ub = block_focal_union(wb, &s_box[0][0], wave, lane);
+    if (level == 1u) {
+      bb = ub;
+    } else {                                         // the tile of wave 0, as that wave sees it
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { bb.lo[i] = s_box[0][i]; bb.hi[i] = s_box[0][3 + i]; }
+      bb.ok = s_box[0][6] != 0.0f; bb.any = s_box[0][7] != 0.0f;
+    }
+  }
+  const TileFamily fam = make_family<SL>(p, bb);
+  if (threadIdx.x == 0u) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { o[i] = bb.lo[i]; o[3 + i] = bb.hi[i]; o[10 + i] = fam.orad[i]; o[13 + i] = fam.fc[i]; }
+    o[6] = fam.lmin; o[7] = fam.lmax; o[8] = fam.usable ? 1.0f : 0.0f; o[9] = fam.A;
+  }
+  for (uint32_t tri = threadIdx.x; tri < p.n_tris; tri += 256u) {
+    const float4 A0 = p.tri_a[2u * tri], A1 = p.tri_a[2u * tri + 1u];
+    const float bz = p.tri_b[tri];
+    float* const r = o + 16u + static_cast<size_t>(tri) * stride;
+    float ends[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if constexpr (FORMS) {
+      float forms[18];
+#pragma unroll
+      for (int i = 0; i < 18; ++i) forms[i] = 0.0f;
+      bool keep = true;
+      if (fam.usable) keep = !tile_misses_triangle<true, false, SL>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z}, forms, nullptr, nullptr, ends);
+      r[0] = keep ? 1.0f : 0.0f;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) r[1 + i] = ends[i];
+#pragma unroll
+      for (int i = 7; i < 12; ++i) r[i] = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) r[12 + i] = forms[i];
+#pragma unroll
+      for (int i = 9; i < 18; ++i) r[12 + i] = __builtin_bit_cast(float, bf16_bits(forms[i]) << 16);
+      r[30] = 0.0f; r[31] = 0.0f;
+    } else {
+      bool keep = true, sure = false;
+      float q[2] = {0.0f, 0.0f};
+      if (fam.usable) keep = !tile_misses_triangle<false, true, SL>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z}, nullptr, &sure, q, ends);
+      r[0] = (keep ? 1.0f : 0.0f) + ((fam.usable && sure) ? 2.0f : 0.0f);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) r[1 + i] = ends[i];
+      r[7] = q[0]; r[8] = q[1]; r[9] = ends[6]; r[10] = ends[7]; r[11] = 0.0f;
+    }
+  }
+}
+
 // fp32 VALU calibration: 8 independent fma chains per lane, 16x unrolled.  Measures the
 // attainable lane-FMA rate of THIS device under load (the honest denominator of the trace
 // kernel's VALU roofline) and the clock it holds (s_memtime ticks / 100 MHz realtime).
@@ -360,6 +439,25 @@ hipError_t launch_dbg_get_ray(bool fma, const TraceParams& p, uint32_t n, const 
   if (n == 0) return hipSuccess;
   if (fma) hipLaunchKernelGGL(dbg_get_ray_kernel<true>, dim3(cdiv(n, 64)), dim3(64), 0, st, p, n, pixels, states, rays);
   else hipLaunchKernelGGL(dbg_get_ray_kernel<false>, dim3(cdiv(n, 64)), dim3(64), 0, st, p, n, pixels, states, rays);
+  return hipGetLastError();
+}
+
+// slack_milli: the scale of every rounding allowance in thousandths -- one of 1000 (the product's), 300, 100, 30, 10, 0
+hipError_t launch_dbg_classify(bool fma, bool forms, uint32_t slack_milli, const TraceParams& p, uint32_t level, uint32_t n_regions,
+                               const uint32_t* regions, float* out, hipStream_t st) {
+  if (n_regions == 0u) return hipSuccess;
+#define RT_CLS(F, FO, M) hipLaunchKernelGGL((dbg_classify_kernel<F, FO, SlackMilli<M>>), dim3(n_regions), dim3(256), 0, st, p, level, regions, out)
+#define RT_CLS_M(F, FO)                                                                     \
+  switch (slack_milli) {                                                                    \
+    case 1000u: RT_CLS(F, FO, 1000); break; case 300u: RT_CLS(F, FO, 300); break;          \
+    case 100u: RT_CLS(F, FO, 100); break;   case 30u: RT_CLS(F, FO, 30); break;            \
+    case 10u: RT_CLS(F, FO, 10); break;     case 0u: RT_CLS(F, FO, 0); break;              \
+    default: return hipErrorInvalidValue;                                                   \
+  }
+  if (fma) { if (forms) { RT_CLS_M(true, true) } else { RT_CLS_M(true, false) } }
+  else { if (forms) { RT_CLS_M(false, true) } else { RT_CLS_M(false, false) } }
+#undef RT_CLS_M
+#undef RT_CLS
   return hipGetLastError();
 }
 

@@ -85,6 +85,8 @@ bool trace_can_fuse(bool filter, bool bin);      // launches with TraceParams::i
 hipError_t launch_macro_bin(const TraceParams& p, bool fma, hipStream_t st);
 hipError_t launch_dbg_check_midrange(unsigned long long* out, hipStream_t st);
 hipError_t launch_dbg_focal_boxes(bool fma, const TraceParams& p, float* boxes, float* focal, hipStream_t st);
+hipError_t launch_dbg_classify(bool fma, bool forms, uint32_t slack_milli, const TraceParams& p, uint32_t level, uint32_t n_regions,
+                               const uint32_t* regions, float* out, hipStream_t st);
 hipError_t launch_dbg_valu_peak(uint32_t blocks, int iters, float* out, unsigned long long* clk, hipStream_t st);
 hipError_t launch_dbg_sincos(uint32_t n, const float* x, float* s, float* c, hipStream_t st);
 hipError_t launch_dbg_uniform(uint32_t n, uint32_t m, uint32_t* states, float* out, hipStream_t st);

@@ -39,8 +39,14 @@ using rtd::V3;
 #ifndef RT_BIN_SLACK_SCALE
 #define RT_BIN_SLACK_SCALE 1.0f
 #endif
-#define RT_SLK(x) (RT_BIN_SLACK_SCALE * (x))
-#define RT_SLKM(x) (1.0f + RT_BIN_SLACK_SCALE * (x))
+// The scale is a compile-time policy of the classification functions: the product instantiates them with SlackProduct
+// (scale 1: `1.0f * x` folds away), the per-(tile, triangle) harness dbg_classify_kernel with the whole ladder
+// 1, 0.3, 0.1, 0.03, 0.01, 0 in ONE library, so that the margin of every allowance is a measured number
+// (tests/test_gpu_classification.py, CLASSIFICATION.md).
+struct SlackProduct { static constexpr float scale = RT_BIN_SLACK_SCALE; };
+template <int MILLI> struct SlackMilli { static constexpr float scale = static_cast<float>(MILLI) / 1000.0f; };
+#define RT_SLK(x) (SL::scale * (x))
+#define RT_SLKM(x) (1.0f + SL::scale * (x))
 #ifndef RT_TRACE_MIN_WAVES
 #define RT_TRACE_MIN_WAVES 4     // __launch_bounds__ 2nd argument: waves per SIMD the allocator must allow
                                  // (<= 128 VGPRs; measured C3 213 -> 193 us, C4 27.2 -> 24.3 ms vs the 136-VGPR build)
@@ -305,6 +311,7 @@ struct FocalBounds {
   bool any;               // the wave has at least one in-image lane
 };
 
+template <class SL = SlackProduct>
 __device__ __forceinline__ FocalBounds focal_bounds(const TraceParams& p, V3 focal, bool inside) {
   FocalBounds b;
   const float fl[3] = {focal.x, focal.y, focal.z};
@@ -336,8 +343,35 @@ __device__ __forceinline__ FocalBounds focal_bounds(const TraceParams& p, V3 foc
   return b;
 }
 
+// Block level of the classification: the union of the four waves' focal bounds (bbox: 4 x 8 floats of LDS; contains a
+// __syncthreads(), so every wave of the block calls it).
+__device__ __forceinline__ FocalBounds block_focal_union(const FocalBounds& wb, float* bbox, uint32_t wave, uint32_t lane) {
+  if (lane == 0u) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { bbox[wave * 8u + i] = wb.lo[i]; bbox[wave * 8u + 3 + i] = wb.hi[i]; }
+    bbox[wave * 8u + 6] = wb.ok ? 1.0f : 0.0f;
+    bbox[wave * 8u + 7] = wb.any ? 1.0f : 0.0f;
+  }
+  __syncthreads();
+  FocalBounds bb;
+  bb.ok = true; bb.any = false;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { bb.lo[i] = FLT_MAX; bb.hi[i] = -FLT_MAX; }
+  for (uint32_t w = 0; w < 4u; ++w) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      bb.lo[i] = fminf(bb.lo[i], bbox[w * 8u + i]);
+      bb.hi[i] = fmaxf(bb.hi[i], bbox[w * 8u + 3 + i]);
+    }
+    bb.ok = bb.ok && (bbox[w * 8u + 6] != 0.0f);
+    bb.any = bb.any || (bbox[w * 8u + 7] != 0.0f);
+  }
+  return bb;
+}
+
 // Ray family over every sample of every pixel inside the focal bounds.  o = pos + (dx*aperture,
 // dy*aperture, 0) with |dx|,|dy| <= 1.0000003 (sr <= 1, build-owned sincos within 2 ulp of [-1,1]).
+template <class SL = SlackProduct>
 __device__ __forceinline__ TileFamily make_family(const TraceParams& p, const FocalBounds& b) {
   TileFamily f;
   const float A = __builtin_fabsf(p.aperture) * RT_SLKM(2e-6f);
@@ -365,6 +399,9 @@ __device__ __forceinline__ TileFamily make_family(const TraceParams& p, const Fo
   f.usable = b.ok && b.any && (A <= FLT_MAX) && (f.lmax <= FLT_MAX);
   return f;
 }
+
+// fp32 -> bf16 bits, round to nearest (ties up): how the per-sample forms' gradients are stored in LDS
+__device__ __forceinline__ uint32_t bf16_bits(float x) { return (__builtin_bit_cast(uint32_t, x) + 0x8000u) >> 16; }
 
 // Per-sample forms (FORMS = true, large-scene kernels).  For ONE ray the lens origin is known: do =
 // o - oc exactly (up to the rounding already inside a_r below), only the focal point keeps its box.
@@ -404,9 +441,11 @@ __device__ __forceinline__ TileFamily make_family(const TraceParams& p, const Fo
 // shading (Kernels.cuh:95-99 uses the winner's vertices only, `hitpoint` is unused): every sample's radiance is A's
 // colour.  Its samples keep their RNG draws and their additions, nothing else.  (Not with spheres, smooth normals or
 // the nearest-hit rule, which need t, u, v.)
-template <bool FORMS = false, bool SURE = false>
+// dbg (harness only, null in every product call): the interval ends the verdicts are taken from --
+// {det_lo, det_hi, U_lo, U_hi, V_lo, V_hi, Nt_lo, Nt_hi} (Nt only with SURE).
+template <bool FORMS = false, bool SURE = false, class SL = SlackProduct>
 __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0, V3 e1, V3 e2, float* forms = nullptr,
-                                                     bool* sure_hit = nullptr, float* q = nullptr) {
+                                                     bool* sure_hit = nullptr, float* q = nullptr, float* dbg = nullptr) {
   // rounding allowance relative to the magnitude sums (DESIGN.md 4.1 "Rounding budget": <= ~20 half-ulps are
   // needed, 67 / 84 are charged).  RT_BIN_SLACK_SCALE exists for the teeth test of the adversarial campaign only
   // (tools/stress_boundaries.py against a build with the allowance scaled down must FIND mismatches).
@@ -515,12 +554,16 @@ __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0,
   const float det_hi = detc + det_rad;
   const float U_lo = Uc - U_rad, U_hi = Uc + U_rad, V_lo = Vc - V_rad, V_hi = Vc + V_rad;
   const float neg = det_hi * -1e-6f, big = det_hi * 1.0002f;
+  if (dbg != nullptr) {
+    dbg[0] = detc - det_rad; dbg[1] = det_hi; dbg[2] = U_lo; dbg[3] = U_hi; dbg[4] = V_lo; dbg[5] = V_hi;
+  }
   if constexpr (SURE) {
     const float det_lo = detc - det_rad;
     *sure_hit = (det_lo > (RT_EPS * 1.0001f) * f.lmax) && (U_lo >= 1e-4f * det_hi) && (V_lo >= 1e-4f * det_hi) &&
                 ((U_hi + V_hi) <= 0.9999f * det_lo) && (tmag * f.lmax < 1e37f * det_lo);
     const float nt_rad = (Nt_rad + c * tmag) * RT_SLKM(1e-5f);
     const float nt_lo = Ntc - nt_rad, nt_hi = Ntc + nt_rad;
+    if (dbg != nullptr) { dbg[6] = nt_lo; dbg[7] = nt_hi; }
     const float inv_lo = __builtin_amdgcn_rcpf(det_lo), inv_hi = __builtin_amdgcn_rcpf(det_hi);   // (1 ulp: far inside the 1e-4 margin of the comparison)
     q[0] = (nt_lo >= 0.0f) ? nt_lo * inv_hi : nt_lo * inv_lo;
     q[1] = (det_lo > 0.0f) ? ((nt_hi >= 0.0f) ? nt_hi * inv_lo : nt_hi * inv_hi) : __builtin_inff();
@@ -541,12 +584,11 @@ __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0,
 // conservative test as the block and wave levels, so the result stays bit-identical to the
 // full scan.  Runs once per launch (the camera may have changed): N x macro tiles tests.
 // ------------------------------------------------------------------------------------
+// Focal bounds of the pixel rectangle [x0, x0 + p.macro_w) x [y0, y0 + p.macro_h) of the band (clipped to it), by all 256
+// threads of the block: every pixel's focal point exactly as the trace kernel computes it.  s_box: 4 x 8 floats of LDS.
 template <bool FMA>
-__global__ __launch_bounds__(256) void macro_bin_kernel(TraceParams p) {
-  __shared__ float s_box[4][8];
-  __shared__ uint32_t s_cnt[2][4];
+__device__ __forceinline__ FocalBounds macro_focal_bounds(const TraceParams& p, uint32_t x0, uint32_t y0, float (*s_box)[8]) {
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const uint32_t x0 = blockIdx.x * p.macro_w, y0 = blockIdx.y * p.macro_h;
   const uint32_t x1 = (x0 + p.macro_w < p.W) ? x0 + p.macro_w : p.W;
   const uint32_t y1 = (y0 + p.macro_h < p.rows) ? y0 + p.macro_h : p.rows;
   const uint32_t w = x1 - x0, count_px = w * (y1 - y0);
@@ -586,6 +628,15 @@ __global__ __launch_bounds__(256) void macro_bin_kernel(TraceParams p) {
     }
     bb.ok = bb.ok && (s_box[v][6] != 0.0f);
   }
+  return bb;
+}
+
+template <bool FMA>
+__global__ __launch_bounds__(256) void macro_bin_kernel(TraceParams p) {
+  __shared__ float s_box[4][8];
+  __shared__ uint32_t s_cnt[2][4];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const FocalBounds bb = macro_focal_bounds<FMA>(p, blockIdx.x * p.macro_w, blockIdx.y * p.macro_h, s_box);
   const TileFamily fam = make_family(p, bb);
   uint32_t* const out = p.macro_lists + (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * (p.macro_cap + 1u);
   const uint32_t n = p.n_tris;
@@ -768,26 +819,7 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
     tl_mark(10);
     if constexpr (!ONEPASS) {
       if (Lb != 0u) {
-        if (lane == 0u) {
-#pragma unroll
-          for (int i = 0; i < 3; ++i) { bbox[wave * 8u + i] = wb.lo[i]; bbox[wave * 8u + 3 + i] = wb.hi[i]; }
-          bbox[wave * 8u + 6] = wb.ok ? 1.0f : 0.0f;
-          bbox[wave * 8u + 7] = wb.any ? 1.0f : 0.0f;
-        }
-        __syncthreads();
-        FocalBounds bb;
-        bb.ok = true; bb.any = false;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { bb.lo[i] = FLT_MAX; bb.hi[i] = -FLT_MAX; }
-        for (uint32_t w = 0; w < 4u; ++w) {
-#pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            bb.lo[i] = fminf(bb.lo[i], bbox[w * 8u + i]);
-            bb.hi[i] = fmaxf(bb.hi[i], bbox[w * 8u + 3 + i]);
-          }
-          bb.ok = bb.ok && (bbox[w * 8u + 6] != 0.0f);
-          bb.any = bb.any || (bbox[w * 8u + 7] != 0.0f);
-        }
+        const FocalBounds bb = block_focal_union(wb, bbox, wave, lane);
         const TileFamily bfam = make_family(p, bb);
         uint32_t total = 0;
         bool overflow = false;
@@ -862,10 +894,7 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
         cI[pos] = static_cast<int>(tri);
         if constexpr (PRETEST && WF) {
           if (pretest) {
-            auto bf = [](float x) {                                  // fp32 -> bf16, round to nearest (ties up)
-              return (__builtin_bit_cast(uint32_t, x) + 0x8000u) >> 16;
-            };
-            auto pk = [&](float hi, float lo) { return __builtin_bit_cast(float, (bf(hi) << 16) | bf(lo)); };
+            auto pk = [&](float hi, float lo) { return __builtin_bit_cast(float, (bf16_bits(hi) << 16) | bf16_bits(lo)); };
             cP[4u * pos] = make_float4(forms[0], forms[1], forms[2], forms[3]);
             cP[4u * pos + 1u] = make_float4(forms[4], forms[5], forms[6], forms[7]);
             cP[4u * pos + 2u] = make_float4(forms[8], pk(forms[9], forms[10]), pk(forms[11], forms[12]), pk(forms[13], forms[14]));

@@ -1635,6 +1635,29 @@ int rt_dbg_focal_boxes(rt_tracer* t, float curv_scale, float* boxes, size_t boxe
   });
 }
 
+int rt_dbg_classify(rt_tracer* t, uint32_t level, uint32_t forms, uint32_t slack_milli, const uint32_t* regions, uint32_t n_regions,
+                    float* out, size_t capacity_floats) {
+  if (!t || t->mg || !regions || !out || level > 2u) return RT_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(t->api_mu);
+  return guarded(t, [&] {
+    t->cancel_and_join();
+    t->use_device();
+    rtk::TraceParams p = t->params(1);
+    p.macro_w = rt_tracer::kMacroW; p.macro_h = rt_tracer::kMacroH;      // level 2: the macro tile of attach_macro_lists
+    const uint32_t rw = level == 0u ? 8u : level == 1u ? 32u : p.macro_w, rh = level == 2u ? p.macro_h : 8u;
+    for (uint32_t i = 0; i < n_regions; ++i)                             // the kernel's pixel <-> lane mapping assumes the trace grid
+      if (regions[2u * i] % rw != 0u || regions[2u * i + 1u] % rh != 0u || regions[2u * i] >= t->W || regions[2u * i + 1u] >= t->rows)
+        throw HipFail{fmt("region %u (%u, %u) is not a level-%u region of the %ux%u band", i, regions[2u * i], regions[2u * i + 1u], level, t->W, t->rows)};
+    const size_t per = 16u + static_cast<size_t>(t->n_tris) * (forms ? 32u : 12u);
+    if (per * n_regions > capacity_floats) throw HipFail{fmt("rt_dbg_classify needs %zu floats", per * n_regions)};
+    DevBuf dr(static_cast<size_t>(n_regions) * 2u * sizeof(uint32_t)), dout(per * n_regions * sizeof(float));
+    HIP_CHECK(hipMemcpyAsync(dr.p, regions, static_cast<size_t>(n_regions) * 2u * sizeof(uint32_t), hipMemcpyHostToDevice, t->main_stream()));
+    HIP_CHECK(rtk::launch_dbg_classify(t->fma, forms != 0u, slack_milli, p, level, n_regions, dr.as<uint32_t>(), dout.as<float>(), t->main_stream()));
+    HIP_CHECK(hipStreamSynchronize(t->main_stream()));
+    HIP_CHECK(hipMemcpy(out, dout.p, per * n_regions * sizeof(float), hipMemcpyDeviceToHost));
+  });
+}
+
 void rt_dbg_rng_init_host(uint64_t seed, uint64_t subsequence, uint32_t state[6]) {
   rth::init_state(jump_host(), seed, subsequence & 0xffffffffull, state);
 }
