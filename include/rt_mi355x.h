@@ -173,6 +173,11 @@ int  rt_tracer_set_image_mirror(rt_tracer* t, void* device_visible_image);
  * (see rt_tracer_stream_b) the upper half-frame kernel's, whose execution overlaps the lower half's.  reset_after != 0
  * clears both and makes the next launch a sampled one. */
 int  rt_tracer_kernel_time(rt_tracer* t, double* total_ms, uint64_t* launches, int reset_after);
+/* The same sampled launches by what they COST: a split launch counts from the start of its upper half to the end of the
+ * LATER of its two halves (the lower half runs on rt_tracer_stream_b), an unsplit launch as above.  This is what the load
+ * balancer uses (rt_tracer_rebalance, RowBandJob.rebalance): a band whose expensive rows lie in its lower half must not look
+ * cheap.  Shares its sample set and its reset with rt_tracer_kernel_time. */
+int  rt_tracer_launch_time(rt_tracer* t, double* total_ms, uint64_t* launches, int reset_after);
 /* One instrumented launch (clear + trace of `samples` spp with counters; not a timed path).
  * Lane-level counters need RT_FLAG_NO_FILTER (reference-order path), wave-level ones the
  * default filtered path:

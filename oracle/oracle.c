@@ -14,7 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__) && !defined(ORC_NO_CLONES)
 /* one clone with hardware FMA (fmaf inlines to vfmadd), one generic (libm fmaf, exact too) */
 #define ORC_CLONES __attribute__((target_clones("fma", "default")))
 #else

@@ -9,6 +9,7 @@ module raises.  PyTorch is not involved here at all.
 import ctypes as C
 import os
 import threading
+import weakref
 
 import numpy as np
 
@@ -34,7 +35,7 @@ ABI_SYMBOLS = [
     "rt_tracer_set_finished_callback", "rt_tracer_wait", "rt_tracer_set_seed",
     "rt_tracer_upload_spheres", "rt_tracer_trace_enqueue", "rt_tracer_sync", "rt_tracer_trace_stats", "rt_tracer_launch", "rt_tracer_launch_iterations", "rt_tracer_fused_iterations", "rt_tracer_set_image_mirror", "rt_tracer_set_list_reuse", "rt_tracer_stream_b", "rt_tracer_upload_scene_edges", "rt_pack_normal",
     "rt_unpack_normal",
-    "rt_tracer_kernel_time", "rt_tracer_read_buffer", "rt_tracer_copy_buffer_to_device", "rt_tracer_copy_buffer_to_device_async",
+    "rt_tracer_kernel_time", "rt_tracer_launch_time", "rt_tracer_read_buffer", "rt_tracer_copy_buffer_to_device", "rt_tracer_copy_buffer_to_device_async",
     "rt_tracer_stream",
     "rt_tracer_device_pointer", "rt_tracer_buffer_bytes", "rt_tracer_info",
     "rt_tracer_last_error", "rt_last_error", "rt_device_count", "rt_version",
@@ -141,6 +142,7 @@ def load_library():
         L.rt_tracer_set_list_reuse.argtypes = [vp, C.c_int]
         L.rt_tracer_trace_stats.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64)]
         L.rt_tracer_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
+        L.rt_tracer_launch_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
         L.rt_tracer_read_buffer.argtypes = [vp, C.c_int, vp, C.c_size_t]
         L.rt_tracer_copy_buffer_to_device.argtypes = [vp, C.c_int, vp, C.c_size_t]
         L.rt_tracer_copy_buffer_to_device_async.argtypes = [vp, C.c_int, vp, C.c_size_t]
@@ -259,6 +261,7 @@ class RayTracer:
         if rc != 0 or not self._h:
             raise RtError("rt_tracer_create failed (%d): %s" % (rc, self._lib.rt_last_error().decode()))
         self.full_height = int(full_height) if full_height else int(size[1])
+        self._band = bool(full_height) and devices is None
         self.width = int(size[0])
         self.rows = int(size[1])
 
@@ -273,6 +276,8 @@ class RayTracer:
         s = np.array(size, np.uint32)
         self._check(self._lib.rt_tracer_resize(self._h, _u32p(s)))
         self.width, self.rows = int(s[0]), int(s[1])
+        if not self._band:                      # whole-frame and multi-device handles: the frame IS the new size
+            self.full_height = self.rows
 
     def SetCameraParameters(self, fov, focalLength, aperture):
         self._lib.rt_tracer_set_camera_parameters(self._h, fov, focalLength, aperture)
@@ -359,6 +364,12 @@ class RayTracer:
     def KernelTime(self, reset=True):
         ms, n = C.c_double(), C.c_uint64()
         self._lib.rt_tracer_kernel_time(self._h, C.byref(ms), C.byref(n), 1 if reset else 0)
+        return ms.value, n.value
+
+    def LaunchTime(self, reset=True):
+        """(total ms, launches) of the sampled launches by their cost: split launches to the end of the later half (rt_tracer_launch_time)."""
+        ms, n = C.c_double(), C.c_uint64()
+        self._lib.rt_tracer_launch_time(self._h, C.byref(ms), C.byref(n), 1 if reset else 0)
         return ms.value, n.value
 
     def _read(self, which, dtype, shape):
@@ -526,11 +537,15 @@ class RayTracer:
             setter(self._h, self._cbs[key], None)
             return
 
+        me = weakref.ref(self)                 # no cycle self -> _cbs -> thunk -> closure -> self: a tracer that is dropped
+                                               # without close() is still freed by its reference count
+
         def tramp(ptr, size, _user):
             n = size // 4
             img = np.ctypeslib.as_array(ptr, shape=(n,))
-            rows, width = self.rows, self.width            # read per call: Resize changes them
-            callback(img.reshape(rows, width) if n == rows * width else img, size)
+            owner = me()
+            rows, width = (owner.rows, owner.width) if owner is not None else (0, 0)   # read per call: Resize changes them
+            callback(img.reshape(rows, width) if n == rows * width and n else img, size)
         self._cbs[key] = CALLBACK(tramp)       # keep alive
         setter(self._h, self._cbs[key], None)
 

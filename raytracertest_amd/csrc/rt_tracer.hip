@@ -206,6 +206,7 @@ struct rt_tracer {
   std::vector<EventPair> free_events;
   uint64_t next_event_seq = 0;
   double kernel_ms = 0.0;
+  double span_ms = 0.0;             // same sampled launches, each counted to the end of the later of its halves
   uint64_t kernel_launches = 0;
 
   std::mutex err_mu;
@@ -384,7 +385,7 @@ struct rt_tracer {
     EventPair e{};
     HIP_CHECK(hipEventCreate(&e.a));
     HIP_CHECK(hipEventCreate(&e.b));
-    HIP_CHECK(hipEventCreateWithFlags(&e.c, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreate(&e.c));         // timed as well: the cost of a split launch is the later of its two halves (span_ms)
     return e;
   }
 
@@ -478,7 +479,14 @@ struct rt_tracer {
     for (size_t i = 0; i < n_done; ++i) {
       EventPair& e = pending[i];
       float ms = 0.0f;
-      if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { kernel_ms += ms; kernel_launches += e.launches; }
+      if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+        kernel_ms += ms; kernel_launches += e.launches;
+        // what the launch COST: for a split launch from the start of the upper half to the end of the later half (the
+        // lower half runs on stream_b; a band whose expensive rows sit there must not look cheap to the load balancer)
+        float lower = 0.0f;
+        if (e.split && hipEventElapsedTime(&lower, e.a, e.c) == hipSuccess && lower > ms) ms = lower;
+        span_ms += ms;
+      }
       free_events.push_back(e);
     }
     pending.erase(pending.begin(), pending.begin() + static_cast<std::ptrdiff_t>(n_done));
@@ -1278,7 +1286,21 @@ int rt_tracer_kernel_time(rt_tracer* t, double* total_ms, uint64_t* launches, in
   std::lock_guard<std::mutex> lk(t->time_mu);
   if (total_ms) *total_ms = t->kernel_ms;
   if (launches) *launches = t->kernel_launches;
-  if (reset_after) { t->kernel_ms = 0.0; t->kernel_launches = 0; t->launch_counter = 0; }   // next launch is sampled
+  if (reset_after) { t->kernel_ms = 0.0; t->span_ms = 0.0; t->kernel_launches = 0; t->launch_counter = 0; }   // next launch is sampled
+  return RT_OK;
+}
+
+int rt_tracer_launch_time(rt_tracer* t, double* total_ms, uint64_t* launches, int reset_after) {
+  if (!t) return RT_ERR_INVALID;
+  if (t->mg) {
+    const int rc = rt_tracer_launch_time(t->mg->bands[0], total_ms, launches, reset_after);
+    if (reset_after) for (size_t k = 1; k < t->mg->bands.size(); ++k) (void)rt_tracer_launch_time(t->mg->bands[k], nullptr, nullptr, 1);
+    return rc;
+  }
+  std::lock_guard<std::mutex> lk(t->time_mu);
+  if (total_ms) *total_ms = t->span_ms;
+  if (launches) *launches = t->kernel_launches;
+  if (reset_after) { t->kernel_ms = 0.0; t->span_ms = 0.0; t->kernel_launches = 0; t->launch_counter = 0; }
   return RT_OK;
 }
 
@@ -1412,7 +1434,7 @@ int rt_tracer_rebalance(rt_tracer* t) {
     for (uint32_t k = 0; k < n; ++k) {
       begins[k] = m.group.bands[k].row0;
       std::lock_guard<std::mutex> tl(m.bands[k]->time_mu);
-      cost[k] = m.bands[k]->kernel_launches ? m.bands[k]->kernel_ms / static_cast<double>(m.bands[k]->kernel_launches) : 0.0;
+      cost[k] = m.bands[k]->kernel_launches ? m.bands[k]->span_ms / static_cast<double>(m.bands[k]->kernel_launches) : 0.0;
     }
     begins[n] = t->H;
     for (uint32_t k = 0; k < n; ++k) if (!(cost[k] > 0.0)) throw HipFail{"rt_tracer_rebalance: no timed launch on every band yet"};

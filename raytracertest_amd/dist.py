@@ -282,10 +282,14 @@ class RowBandJob:
             return [b["rows"] for b in self.tracer.Bands()]
         import torch
         from .api import balance_rows
-        ms, n = self.tracer.KernelTime(reset=True)
-        mine = torch.tensor([ms / max(n, 1), float(self.row0), float(self.rows)], dtype=torch.float64)
+        ms, n = self.tracer.LaunchTime(reset=True)          # split launches count to the end of their later half
+        mine = torch.tensor([ms / max(n, 1), float(self.row0), float(self.rows), float(n)], dtype=torch.float64)
         every = [torch.zeros_like(mine) for _ in range(self.world)]
         self.dist.all_gather(every, mine)
+        idle = [k for k, t in enumerate(every) if t[3].item() == 0]
+        if idle:                                            # (same verdict on every rank: nobody is left in a collective)
+            raise RuntimeError("rebalance: ranks %s have no sampled launch since the last reset (a cost of 0 would shrink their "
+                               "bands to one granule)" % idle)
         begins = [int(t[1].item()) for t in every] + [self.full_height]
         fresh = balance_rows(begins, [float(t[0].item()) for t in every], 8)
         if fresh != begins:

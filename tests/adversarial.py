@@ -97,10 +97,14 @@ def _pick_ray(rng, cam, W, H):
     return o, d, focal, dc
 
 
-def adversarial_triangles(rng, cam, W, H, n, scale):
+KINDS_DEFAULT = (0.18, 0.18, 0.09, 0.1, 0.1, 0.23, 0.12)
+KINDS_COVER = (0.08, 0.05, 0.02, 0.05, 0.1, 0.1, 0.6)     # mostly covers: scenes whose tiles have certain winners
+
+
+def adversarial_triangles(rng, cam, W, H, n, scale, kinds_p=KINDS_DEFAULT):
     """(n, 3, 3) float32 triangles around the rays of the camera's tile families (see the module docstring)."""
     tris = np.zeros((n, 3, 3), np.float64)
-    kinds = rng.choice(7, n, p=[0.18, 0.18, 0.09, 0.1, 0.1, 0.23, 0.12])
+    kinds = rng.choice(7, n, p=list(kinds_p))
     jitter = rng.choice([0, 1, 2, 4, 16, 64], n, p=[0.15, 0.2, 0.2, 0.2, 0.15, 0.1])
     last_cover = None
     for i in range(n):
@@ -178,6 +182,21 @@ def adversarial_triangles(rng, cam, W, H, n, scale):
         if sel.any():
             out[sel] = ulp_jitter(rng, out[sel], k)
     return out
+
+
+def cover_config(rng):
+    """A configuration aimed at the certain-winner verdict: a few to 64 triangles, most of them covering a tile's whole
+    ray family by a margin of 0 ... 1 of its size, half of those stacked 0 ... 1e-2 apart in depth; moderate apertures so
+    that covers exist at all."""
+    scale = float(10.0 ** rng.uniform(-3, 4))
+    W, H = int(rng.integers(9, 73)), int(rng.integers(9, 49))
+    cam = dict(angles=(float(rng.uniform(-3.2, 3.2)), float(rng.uniform(-3.2, 3.2))), fov=float(rng.uniform(5, 120)),
+               focal=float(scale * 10.0 ** rng.uniform(-1, 1)),
+               aperture=float(scale * rng.choice([0.0, 1e-4, 1e-3, 0.01, 0.03])))
+    n = int(rng.choice([3, 8, 20, 40, 64]))
+    tris = adversarial_triangles(rng, cam, W, H, n, scale, KINDS_COVER)
+    return dict(scale=scale, W=W, H=H, cam=cam, tris=tris, mode=int(rng.integers(0, 2)), spp=int(rng.integers(1, 9)),
+                iters=int(rng.integers(1, 3)), seed=int(rng.integers(1, 1 << 30)), nearest=False)
 
 
 def adversarial_config(rng, large=False):

@@ -91,6 +91,7 @@ class Tally:
         self.regions = self.pairs = self.rays = 0
         self.dropped = self.kept = self.sure = self.sure_tiles = 0
         self.bad = {s: {"drop_hit": 0, "drop_win": 0, "sure_miss": 0, "tile_winner": 0} for s in LADDER}
+        self.scales = set()             # the scales of the ladder this tally was run at
         self.contain_bad = 0            # (c) at the product's allowances
         self.q_bad = 0
         self.form_wrong = 0
@@ -108,6 +109,7 @@ class Tally:
         for s in LADDER:
             for k in self.bad[s]:
                 self.bad[s][k] += o.bad[s][k]
+        self.scales |= o.scales
         self.needed = max(self.needed, o.needed)
         self.needed_q = max(self.needed_q, o.needed_q)
         for k in self.needed_by:
@@ -118,6 +120,8 @@ class Tally:
         """smallest scale of the ladder (as a fraction) down to which (a) and (b) hold without exception"""
         ok = 1.0
         for s in LADDER:
+            if s not in self.scales:
+                continue
             if any(self.bad[s].values()):
                 break
             ok = s / 1000.0
@@ -127,7 +131,7 @@ class Tally:
         return {"regions": self.regions, "tile_triangle_pairs": self.pairs, "rays_per_pair_total": self.rays,
                 "dropped_pairs": self.dropped, "kept_pairs": self.kept, "certainly_hit_pairs": self.sure,
                 "certain_winner_tiles": self.sure_tiles,
-                "violations_by_scale": {str(s / 1000.0): dict(self.bad[s]) for s in LADDER},
+                "violations_by_scale": {str(s / 1000.0): dict(self.bad[s]) for s in LADDER if s in self.scales},
                 "smallest_passing_scale": self.smallest_passing_scale(),
                 "containment_violations_at_scale_1": self.contain_bad, "q_violations_at_scale_1": self.q_bad,
                 "needed_scale": round(self.needed, 5), "needed_scale_by_quantity": {k: round(v, 5) for k, v in self.needed_by.items()},
@@ -165,6 +169,7 @@ def check_region(tag, probe, nohit, rays, recs, hdrs, forms=False, tile_word=Non
     for s in LADDER:
         if s not in recs:
             continue
+        t.scales.add(s)
         fl = recs[s][:, 0].astype(np.int32)
         keep, sure = (fl & 1) != 0, (fl & 2) != 0
         b = t.bad[s]

@@ -71,6 +71,9 @@ class OracleBackedTracer:
     def KernelTime(self, reset=True):
         return 0.0, 0
 
+    def LaunchTime(self, reset=True):
+        return 0.0, 0
+
     def GatherTime(self, reset=True):
         return 0.0, 0
 

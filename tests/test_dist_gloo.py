@@ -216,7 +216,7 @@ def test_row_band_job_over_two_ranks_with_an_oracle_backed_tracer(tmp_path, orc,
 
 
 # ---------------------------------------------------------------- the product exchange's host logic (id hand-out, re-partition)
-def _native_exchange_worker(rank, world, port, outdir):
+def _native_exchange_worker(rank, world, port, outdir, idle=False):
     import sys, json
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -232,13 +232,22 @@ def _native_exchange_worker(rank, world, port, outdir):
         def JoinGroup(self, n, r, uid, row_begin=None): log.append(("join", n, r, uid.hex() if uid else None, row_begin))
         def LeaveGroup(self): log.append(("leave",))
         def SetBand(self, row0, rows): log.append(("band", row0, rows)); self.row0, self.rows = row0, rows
-        def KernelTime(self, reset=True): return (2.0 if rank == 0 else 6.0), 2     # rank 1's band is three times as expensive
+        def LaunchTime(self, reset=True): return (2.0 if rank == 0 else 6.0), (0 if idle and rank == 1 else 2)   # rank 1's band is three times as expensive
         def close(self): pass
 
     cfg = dict(width=16, height=64, iterations=1, samples=1, angles=(0.0, 0.0), fov=70.0, focal=3.0, aperture=0.05, seed=1)
     job = RowBandJob(cfg, scenes.cornell32(), np.zeros((0, 4), np.float32), world=world, rank=rank, local_rank=rank, weak=False,
                      exchange=NativeExchange(),
                      tracer_factory=lambda device=0, full_height=0, row_begin=0, **kw: FakeTracer(row_begin, full_height // world))
+    if idle:                     # a rank without a sampled launch: every rank raises, nobody stays behind in a collective
+        try:
+            job.rebalance()
+            err = None
+        except RuntimeError as e:
+            err = str(e)
+        json.dump({"error": err, "log": log}, open(os.path.join(outdir, "ex%d.json" % rank), "w"))
+        job.close()
+        return
     rows = job.rebalance()
     json.dump({"log": log, "rows": rows, "mine": [job.row0, job.rows]}, open(os.path.join(outdir, "ex%d.json" % rank), "w"))
     job.close()
@@ -259,3 +268,15 @@ def test_native_exchange_hands_out_the_id_and_rebalances_consistently(tmp_path):
         assert r[k]["log"][1] == ["leave"] and r[k]["log"][2][0] == "band"
         assert r[k]["log"][3] == ["join", 2, k, uid, [0, 40, 64]]
     assert r[0]["rows"] == r[1]["rows"] == [40, 24] and r[0]["mine"] == [0, 40] and r[1]["mine"] == [40, 24]
+
+
+@pytest.mark.timeout(300)
+def test_rebalance_refuses_a_rank_without_a_sampled_launch(tmp_path):
+    """a rank that reports no sampled launch would get cost 0 and be shrunk to one granule; every rank raises
+    the same error instead (no rank is left waiting in a collective)."""
+    import json
+    import torch.multiprocessing as mp
+    mp.spawn(_native_exchange_worker, args=(2, _free_port(), str(tmp_path), True), nprocs=2, join=True)
+    r = [json.load(open(os.path.join(str(tmp_path), "ex%d.json" % k))) for k in range(2)]
+    for k in range(2):
+        assert r[k]["error"] and "[1]" in r[k]["error"] and len(r[k]["log"]) == 1      # joined once, never left or moved

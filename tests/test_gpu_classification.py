@@ -12,11 +12,12 @@ import numpy as np
 import pytest
 
 import classification_check as cc
-from adversarial import adversarial_config
+from adversarial import adversarial_config, cover_config
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REPORT = {}
+N_ADV, N_COVER = 100, 60
 
 
 @pytest.fixture(scope="module")
@@ -59,7 +60,7 @@ def clean(t, what):
 
 
 def test_adversarial_scenes_per_tile_and_triangle(rt, orc):
-    """40 adversarial configurations (tests/adversarial.py: triangles aimed at the decision boundaries of the tiles' ray
+    """100 adversarial configurations + 60 aimed at the certain-winner verdict (tests/adversarial.py: triangles aimed at the decision boundaries of the tiles' ray
     families, coordinate scales 1e-3 ... 1e4, apertures 0 ... 100 x the scene, both arithmetic modes): every tile of the
     frame x every triangle.  Small scenes also cross-check rt_dbg_classify against the lists and certain-winner verdicts the
     PRODUCT launch stored (rt_dbg_read_tile_lists): the harness sees what the trace kernel decided."""
@@ -67,8 +68,8 @@ def test_adversarial_scenes_per_tile_and_triangle(rt, orc):
     rng = np.random.default_rng(20261)
     lens = cc.lens_samples(orc, seed=5, pixel_index=11)
     total, onepass = cc.Tally(), 0
-    for it in range(40):
-        c = adversarial_config(rng)
+    for it in range(N_ADV + N_COVER):
+        c = adversarial_config(rng) if it < N_ADV else cover_config(rng)
         n = c["tris"].shape[0]
         g, o = pair(rt, orc, c["W"], c["H"], scenes._tri_rows(c["tris"]), c["cam"], c["mode"], seed=c["seed"])
         stored = None
@@ -82,9 +83,9 @@ def test_adversarial_scenes_per_tile_and_triangle(rt, orc):
             total.merge(cc.run(g, o, [(x, y) for y in range(0, c["H"], 8) for x in range(0, c["W"], 32)], 1, lens, tag="adv%d" % it))
         g.close()
     s = clean(total, "adversarial scenes")
-    s["configurations"], s["with_product_lists_cross_checked"] = 40, onepass
+    s["configurations"], s["with_product_lists_cross_checked"] = N_ADV + N_COVER, onepass
     REPORT["adversarial"] = s
-    assert total.dropped > 0 and total.sure > 0 and total.sure_tiles > 0
+    assert total.dropped > 0 and total.sure > 100 and total.sure_tiles > 50
     # teeth: with no rounding allowance at all the reference's values DO leave the intervals (the test can see rounding),
     # and the product charges a multiple of what they need
     assert total.needed > 0.0, "the probe never reaches the zero-allowance intervals: no teeth"

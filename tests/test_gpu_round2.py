@@ -236,6 +236,7 @@ def test_multi_device_callbacks_resize_camera_and_stop(rt, orc):
     g.Trace(2, 2, 0); assert g.Wait()
     o2.trace(2, 2)
     assert_frame_equal(g, o2)
+    assert np.array_equal(g.Frame(), o2.image)          # (Frame() after Resize uses the NEW height)
     assert [b["rows"] for b in g.Bands()] == [4, 5, 4, 5, 5]
     n_fin = len(finished)
     g.Trace(100000, 1, 0); g.Stop()

@@ -1,0 +1,67 @@
+"""Round-3 GPU parity tests: the launch shape bench.py's headline times, bit-checked at full size against the committed
+golden frame and -- the RNG stream continues from step to step -- against the oracle on sampled row bands."""
+import numpy as np
+import pytest
+
+from test_golden import FRAMES, _check, _spec_scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rt():
+    import raytracertest_amd as R
+    from raytracertest_amd import api
+    assert R.device_count() >= 1, "no HIP device: the GPU tests need the real extension"
+    return api
+
+
+def test_c3_headline_launch_shape_at_full_size(rt, orc):
+    """What `python bench.py` times: 1920x1080, list reuse restricted to one Trace, TraceEnqueue(1, 16) = ONE launch split
+    into two half-frame kernels on two streams, accumulators taken as zero (TRACE_ZERO_ACC), BGRA8 emitted by the same
+    launch.  Step 1 == the golden frame C3_full/fma (CRCs of render / counts / RNG states / image + centre crop);
+    steps 2..4 continue the pixels' RNG streams (RayTracerImpl.cu:94-103: states are re-created by Resize only), checked
+    against the oracle on the first rows, the rows across the split (row 544) and the last rows."""
+    spec = FRAMES["C3_full/fma"]["spec"]
+    assert (spec["W"], spec["H"], spec["it"], spec["spp"]) == (1920, 1080, 1, 16)
+    tris, _ = _spec_scene(spec)
+    g = rt.RayTracer((spec["W"], spec["H"]), (0, 0, 0), (0.0, 0.0), spec["fov"], spec["focal"], spec["aperture"], seed=1)
+    assert g.UploadScene(tris)
+    g.SetListReuse(False)
+    g.TraceEnqueue(1, 16); g.Sync()
+    render, counts, rng, image = g.RenderBuffer(), g.SampleCounts(), g.RngStates(), g.Image()
+    _check("C3_full/fma", render, counts, rng, image)
+    steps = 4
+    for _ in range(steps - 1):
+        g.TraceEnqueue(1, 16)
+    g.Sync()
+    render, counts, rng, image = g.RenderBuffer(), g.SampleCounts(), g.RngStates(), g.Image()
+    assert (counts == 16).all() and not render[..., 3].any()
+    for row0, rows in ((0, 8), (536, 16), (1072, 8)):
+        o = orc.OracleTracer(spec["W"], spec["H"], (0.0, 0.0), spec["fov"], spec["focal"], spec["aperture"], seed=1, row0=row0,
+                             rows=rows, contract=1, nthreads=8)
+        o.upload_scene(tris)
+        for _ in range(steps):
+            o.trace(1, 16)
+        sl = slice(row0, row0 + rows)
+        assert np.array_equal(render[sl].view(np.uint32), o.render.view(np.uint32)), "rows %d..: render after %d steps" % (row0, steps)
+        assert np.array_equal(rng[sl], o.rng) and np.array_equal(image[sl], o.image) and np.array_equal(counts[sl], o.counts)
+    g.close()
+
+
+def test_bench_parity_leg_reads_the_same_fixture():
+    """bench.py's parity_check leg (one untimed headline step on a fresh tracer against tests/golden/frames.json)."""
+    import bench
+    import raytracertest_amd as R
+    from raytracertest_amd import scenes
+    cfg = dict(scenes.CONFIGS["C3"])
+    tris, _ = scenes.scene_for("C3")
+    g = R.RayTracer((cfg["width"], cfg["height"]), (0, 0, 0), cfg["angles"], cfg["fov"], cfg["focal"], cfg["aperture"], seed=cfg["seed"])
+    assert g.UploadScene(tris)
+    g.SetListReuse(False)
+    g.TraceEnqueue(cfg["iterations"], cfg["samples"]); g.Sync()
+    rec = bench.parity_check("C3", g)
+    assert rec["fixture"] == "C3_full/fma" and rec["ok"] is True, rec
+    g.TraceEnqueue(cfg["iterations"], cfg["samples"]); g.Sync()       # a second step is another frame: the leg must notice
+    assert bench.parity_check("C3", g)["ok"] is False
+    g.close()

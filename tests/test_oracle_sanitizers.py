@@ -43,3 +43,27 @@ def test_oracle_clean_under_asan_ubsan(tmp_path, orc):
     t.upload_scene(scenes.cornell32()); t.upload_spheres(np.array([[0, 0, -2.5, 0.4]], np.float32))
     t.trace(2, 5)
     assert str(int(t.image.astype(np.uint64).sum())) in out.stdout
+
+
+def test_oracle_threaded_paths_clean_under_tsan(tmp_path):
+    """SURVEY section 5 "race detection": the oracle's row-threaded RNG-state creation and trace launch, the lazily built jump
+    matrices reached from several threads at once, and concurrent orc_tile_probe calls (tests/classification_check.py runs
+    them from a thread pool) under ThreadSanitizer -- a C driver, because TSan cannot be preloaded into CPython.  The driver's
+    checksum must equal the un-instrumented build's."""
+    drv = os.path.join(ROOT, "tests", "cpp", "oracle_tsan_driver.c")
+    src = os.path.join(ROOT, "oracle", "oracle.c")
+    tsan, plain = str(tmp_path / "orc_tsan"), str(tmp_path / "orc_plain")
+    # (the FMA/generic target_clones of oracle.c are ifuncs, resolved before the sanitizer runtime is up: off for this build)
+    b = subprocess.run(["gcc", "-O1", "-g", "-std=gnu11", "-ffp-contract=off", "-DORC_NO_CLONES", "-fsanitize=thread", "-fPIE", "-pie",
+                        "-pthread", "-o", tsan, drv, src, "-lm"], capture_output=True, text=True)
+    if b.returncode != 0 and "tsan" in (b.stderr or "").lower():
+        pytest.skip("libtsan not available: " + b.stderr[-300:])
+    assert b.returncode == 0, b.stderr[-2000:]
+    subprocess.run(["gcc", "-O2", "-std=gnu11", "-ffp-contract=off", "-pthread", "-o", plain, drv, src, "-lm"], check=True)
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0:exitcode=66")
+    out = subprocess.run([tsan], env=env, capture_output=True, text=True, timeout=300)
+    if "unexpected memory mapping" in out.stderr:
+        pytest.skip("ThreadSanitizer cannot map its shadow memory in this container")
+    ref = subprocess.run([plain], capture_output=True, text=True, timeout=300)
+    assert "ThreadSanitizer" not in out.stderr and out.returncode == 0, out.stderr[-3000:]
+    assert out.stdout.startswith("TSAN_DRIVER_OK") and out.stdout == ref.stdout, (out.stdout, ref.stdout)
