@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void dbg_focal_boxes_kernel(const TraceParams 
 // (block_focal_union, the trace kernel's block-level pre-cull); level 2: the macro tile of p.macro_w x p.macro_h pixels
 // at (x0, y0) (macro_focal_bounds, macro_bin_kernel) -- and for EVERY triangle of the scene what
 // tile_misses_triangle decides and the interval ends it decides from, with every rounding allowance scaled by SL::scale.
-//   out[region] = 16 header floats: focal lo[3], hi[3], lmin, lmax, usable, A, orad[3], fc[3]
+//   out[region] = 16 header floats: focal lo[3], hi[3], lmin, lmax, usable (+ 2: the two focal-bound paths agree), A, orad[3], fc[3]
 //               + n_tris x stride floats: flags (1 keep | 2 certainly hit), det_lo, det_hi, U_lo, U_hi, V_lo, V_hi,
 //                 q_lo, q_hi, Nt_lo, Nt_hi, 0 (stride 12; the small-scene instantiation <false, SURE>), or, FORMS:
 //                 flags (1 keep), the same six ends, 5 x 0, then the 18 numbers of the per-sample forms with the gradients
@@ -175,6 +175,7 @@ __global__ __launch_bounds__(256) void dbg_classify_kernel(const TraceParams p, 
   constexpr uint32_t stride = FORMS ? 32u : 12u;
   float* const o = out + static_cast<size_t>(blockIdx.x) * (16u + static_cast<size_t>(p.n_tris) * stride);
   FocalBounds bb;
+  bool paths_agree = true;           // level 0: focal_bounds (trace waves of large scenes) == group_focal_bounds (list builder)
   if (level == 2u) {
     bb = macro_focal_bounds<FMA>(p, x0, y0, s_box);
   } else {
@@ -187,17 +188,20 @@ __global__ __launch_bounds__(256) void dbg_classify_kernel(const TraceParams p, 
     const FocalBounds ub = block_focal_union(wb, &s_box[0][0], wave, lane);
     if (level == 1u) {
       bb = ub;
-    } else {                                         // the tile of wave 0, as that wave sees it
-#pragma unroll
-      for (int i = 0; i < 3; ++i) { bb.lo[i] = s_box[0][i]; bb.hi[i] = s_box[0][3 + i]; }
-      bb.ok = s_box[0][6] != 0.0f; bb.any = s_box[0][7] != 0.0f;
+    } else {
+      // the wave tile at (x0, y0): the bounds tile_lists_kernel builds the tile's list from (small scenes) -- identical to
+      // what the trace wave of a large scene computes for its tile (focal_bounds, wave 0 above: s_box[0]); both are exported
+      // paths of the same arithmetic, the harness takes the list builder's
+      bb = group_focal_bounds<FMA, 64, SL>(p, x0, y0, x0 < p.W, lane, 0u);
+      paths_agree = s_box[0][0] == bb.lo[0] && s_box[0][1] == bb.lo[1] && s_box[0][2] == bb.lo[2] && s_box[0][3] == bb.hi[0] &&
+                    s_box[0][4] == bb.hi[1] && s_box[0][5] == bb.hi[2] && (s_box[0][6] != 0.0f) == bb.ok && (s_box[0][7] != 0.0f) == bb.any;
     }
   }
   const TileFamily fam = make_family<SL>(p, bb);
   if (threadIdx.x == 0u) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) { o[i] = bb.lo[i]; o[3 + i] = bb.hi[i]; o[10 + i] = fam.orad[i]; o[13 + i] = fam.fc[i]; }
-    o[6] = fam.lmin; o[7] = fam.lmax; o[8] = fam.usable ? 1.0f : 0.0f; o[9] = fam.A;
+    o[6] = fam.lmin; o[7] = fam.lmax; o[8] = (fam.usable ? 1.0f : 0.0f) + (paths_agree ? 2.0f : 0.0f); o[9] = fam.A;
   }
   for (uint32_t tri = threadIdx.x; tri < p.n_tris; tri += 256u) {
     const float4 A0 = p.tri_a[2u * tri], A1 = p.tri_a[2u * tri + 1u];
@@ -388,6 +392,21 @@ hipError_t launch_macro_bin(const TraceParams& p, bool fma, hipStream_t st) {
   const dim3 grid(cdiv(p.W, p.macro_w), cdiv(p.rows, p.macro_h));
   if (fma) hipLaunchKernelGGL(macro_bin_kernel<true>, grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL(macro_bin_kernel<false>, grid, dim3(256), 0, st, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_tile_lists(const TraceParams& p, bool fma, hipStream_t st) {
+  if (p.tile_lists == nullptr || p.rows == 0u || p.W == 0u) return hipSuccess;
+  const uint32_t slots = cdiv(p.W, 32) * cdiv(p.rows, 8) * 4u;
+  if (p.n_tris <= 32u) {                                             // two tiles per wave
+    const dim3 grid(cdiv(slots, 8u));
+    if (fma) hipLaunchKernelGGL((tile_lists_kernel<true, 32>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((tile_lists_kernel<false, 32>), grid, dim3(256), 0, st, p);
+  } else {
+    const dim3 grid(cdiv(slots, 4u));
+    if (fma) hipLaunchKernelGGL((tile_lists_kernel<true, 64>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((tile_lists_kernel<false, 64>), grid, dim3(256), 0, st, p);
+  }
   return hipGetLastError();
 }
 

@@ -46,7 +46,8 @@ struct TraceParams {
   // followed by macro_cap ascending triangle indices.  null = no macro level.
   uint32_t* macro_lists;
   uint32_t  macro_cap, macro_w, macro_h, macro_nx;
-  uint32_t* tile_lists; // per wave tile: count + bin_list triangle indices (TRACE_LISTS_*), or null
+  uint32_t* tile_lists; // small scenes: per wave tile count | winner << 10 | certain << 31, then bin_list triangle indices
+                        // (written by tile_lists_kernel, read by the trace kernel); null: no lists (large scene, no triangles)
   uint32_t  flags;     // TRACE_*
 };
 
@@ -57,10 +58,8 @@ constexpr uint32_t TRACE_ZERO_ACC = 1u;
 constexpr uint32_t TRACE_EMIT_IMAGE = 2u;
 // Hit selection: keep the nearest t > 0 instead of the reference's farthest t (build-defined extension).
 constexpr uint32_t TRACE_NEAREST_HIT = 4u;
-// ONEPASS kernels: store each tile's candidate list to TraceParams::tile_lists / load it from there
-// instead of classifying (valid while camera, scene and frame are unchanged; the host decides).
-constexpr uint32_t TRACE_LISTS_STORE = 8u;
-constexpr uint32_t TRACE_LISTS_LOAD = 16u;
+// (8, 16: were TRACE_LISTS_STORE / TRACE_LISTS_LOAD while the small-scene trace kernels classified on their own; the lists
+//  are now always built by tile_lists_kernel and always loaded)
 // large-scene kernels: per-sample conservative forms per candidate (9 more floats per LDS record)
 constexpr uint32_t TRACE_PRETEST = 32u;
 // small-scene kernels: do not skip the intersection tests of tiles whose list is one certainly-hit triangle (A/B, tests)
@@ -83,6 +82,8 @@ hipError_t launch_dbg_hit_triangle(bool fma, uint32_t n, const float* rays, cons
                                    int* hit, float* tuv, float* normal, float* point, hipStream_t st);
 bool trace_can_fuse(bool filter, bool bin);      // launches with TraceParams::iters > 1 are available
 hipError_t launch_macro_bin(const TraceParams& p, bool fma, hipStream_t st);
+// small scenes: the tiles' candidate lists + certain-winner verdicts of the (half-)launch `p` into p.tile_lists
+hipError_t launch_tile_lists(const TraceParams& p, bool fma, hipStream_t st);
 hipError_t launch_dbg_check_midrange(unsigned long long* out, hipStream_t st);
 hipError_t launch_dbg_focal_boxes(bool fma, const TraceParams& p, float* boxes, float* focal, hipStream_t st);
 hipError_t launch_dbg_classify(bool fma, bool forms, uint32_t slack_milli, const TraceParams& p, uint32_t level, uint32_t n_regions,

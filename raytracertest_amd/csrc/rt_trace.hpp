@@ -668,6 +668,178 @@ __global__ __launch_bounds__(256) void macro_bin_kernel(TraceParams p) {
 }
 
 // ------------------------------------------------------------------------------------
+// Small scenes (no more triangles than the per-wave list holds): the tiles' candidate lists and certain-winner
+// verdicts are built by a kernel of their own, ahead of the trace launch that needs them.
+//
+// A tile's list depends on the camera, the scene and the frame, not on the samples: it is a camera-dependent
+// acceleration structure, and building it needs neither RNG states nor rays -- only the tile's ray family, i.e. the focal
+// points of its four corner pixels (full tiles; every in-image pixel otherwise), and one pass of tile_misses_triangle with
+// lane = triangle.  Inside the trace kernel that pass ran once per wave with half of its lanes idle (C3: 32 triangles),
+// behind a 64-pixel pinhole pass, and held the trace kernel's registers while it did: 675 of a C3 tile's 2 565
+// instructions, 58 % of what a certain-winner tile costs.  Here G = 32 or 64 lanes own one tile (two tiles per wave for
+// scenes of up to 32 triangles), the trace kernel's small-scene instantiations contain no classification code at all and
+// a tile with a certain winner generates no pinhole ray either.  The lists are the same ones the wave would have built --
+// same focal_bounds arithmetic (corner path or the range over the in-image pixels), same make_family, same
+// tile_misses_triangle<.., SURE> -- so nothing a trace computes changes (rt_dbg_classify is that same code, checked
+// verdict by verdict against the reference's arithmetic: tests/test_gpu_classification.py).
+//
+// The certain-winner verdict now spans classification steps (scenes of 65 ... 256 triangles): per tile the running
+// winner A = the kept, certainly-hit triangle with the largest lower bound of q (first in scan order on ties) and the
+// two largest upper bounds of q over the kept triangles, so that R = the largest upper bound over the kept triangles
+// other than A is known at the end; the rule itself is unchanged (A alone, or R < Q - 1e-4 (|R| + |Q|)).
+//
+// Per tile slot (grid order of the trace launch, 4 per 32x8 block): word 0 = count | winner << 10 | certain << 31,
+// then the kept triangle indices, ascending.  grid = ceil(slots / (4 * (64 / G))) blocks of 256 threads.
+// ------------------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+  for (int off = G / 2; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+template <int G>
+__device__ __forceinline__ float group_min(float v) {
+#pragma unroll
+  for (int off = G / 2; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// The focal bounds of the 8x8 tile at (x0, y0) of the band for the G lanes that own it (gl = lane within the group, gbase =
+// its first lane): full tiles take the four corner pixels' focal points -- computed exactly as the rays use them -- widened
+// by what a focal point of the tile can lie off the corners' bilinear interpolant (p.tile_curv, host) and by the roundings
+// of the evaluations (see focal_bounds, whose corner path this is); partial tiles (image edge) and cameras the host does not
+// vouch for (p.tile_curv <= 0) take the range over their in-image pixels.  Group-uniform result.
+template <bool FMA, int G, class SL>
+__device__ __forceinline__ FocalBounds group_focal_bounds(const TraceParams& p, uint32_t x0, uint32_t y0, bool in_image, uint32_t gl, uint32_t gbase) {
+  constexpr uint32_t T = 64u / G;
+  const bool full = in_image && x0 + 8u <= p.W && y0 + 8u <= p.rows;
+  FocalBounds b;
+  const bool corners = p.tile_curv > 0.0f && full;                  // group-uniform
+  const unsigned long long need_range = __builtin_amdgcn_ballot_w64(in_image && !corners);
+  {
+    // corner path: lanes 0..3 of the group take the pixels (x0, y0), (x0 + 7, y0), (x0, y0 + 7), (x0 + 7, y0 + 7)
+    const uint32_t cx = x0 + ((gl & 1u) ? 7u : 0u), cy = y0 + ((gl & 2u) ? 7u : 0u);
+    V3 po, pd;
+    pinhole<FMA>(p, cx < p.W ? cx : 0u, p.row0 + (cy < p.rows ? cy : 0u), po, pd);
+    const V3 f = focal_point<FMA>(p, pd);
+    const float fl[3] = {f.x, f.y, f.z};
+    const float dev = p.tile_curv + RT_SLK(4e-6f) * p.tile_round;
+    bool finite = true;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float c0 = __shfl(fl[i], static_cast<int>(gbase), 64), c1 = __shfl(fl[i], static_cast<int>(gbase + 1u), 64);
+      const float c2 = __shfl(fl[i], static_cast<int>(gbase + 2u), 64), c3 = __shfl(fl[i], static_cast<int>(gbase + 3u), 64);
+      b.lo[i] = fminf(fminf(c0, c1), fminf(c2, c3)) - dev;
+      b.hi[i] = fmaxf(fmaxf(c0, c1), fmaxf(c2, c3)) + dev;
+      // (the trace wave asks every in-image lane for a finite focal point; of a full tile's 64 monotone-bounded points
+      // the corners' range +- dev is finite iff they are: lo/hi are checked instead, make_family drops to "keep all")
+      finite = finite && (__builtin_fabsf(b.lo[i]) <= FLT_MAX) && (__builtin_fabsf(b.hi[i]) <= FLT_MAX);
+    }
+    b.ok = finite; b.any = true;
+  }
+  if (need_range != 0ull) {                                         // wave-uniform: some group of this wave has a partial tile
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    bool finite = true, any = false;
+#pragma unroll
+    for (uint32_t i = 0; i < T; ++i) {                              // the 64 pixels of the tile, G at a time
+      const uint32_t pi = gl + i * G;
+      const uint32_t px = x0 + (pi & 7u), py = y0 + (pi >> 3);
+      const bool inside = in_image && px < p.W && py < p.rows;
+      V3 po, pd;
+      pinhole<FMA>(p, inside ? px : 0u, p.row0 + (inside ? py : 0u), po, pd);
+      const V3 f = focal_point<FMA>(p, pd);
+      const float fl[3] = {f.x, f.y, f.z};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if (inside) { lo[c] = fminf(lo[c], fl[c]); hi[c] = fmaxf(hi[c], fl[c]); finite = finite && (__builtin_fabsf(fl[c]) <= FLT_MAX); }
+      }
+      any = any || inside;
+    }
+    const unsigned long long gmask = G == 64 ? ~0ull : (0xFFFFFFFFull << gbase);
+    const bool g_ok = (__builtin_amdgcn_ballot_w64(!finite) & gmask) == 0ull;
+    const bool g_any = (__builtin_amdgcn_ballot_w64(any) & gmask) != 0ull;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { lo[c] = group_min<G>(lo[c]); hi[c] = group_max<G>(hi[c]); }
+    if (!corners) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { b.lo[c] = lo[c]; b.hi[c] = hi[c]; }
+      b.ok = g_ok; b.any = g_any;
+    }
+  }
+  return b;
+}
+
+template <bool FMA, int G, class SL = SlackProduct>
+__global__ __launch_bounds__(256) void tile_lists_kernel(const TraceParams p) {
+  static_assert(G == 32 || G == 64, "lanes per tile");
+  constexpr uint32_t T = 64u / G;                                   // tiles per wave
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t gl = lane & (G - 1u), gbase = lane & ~(G - 1u);    // lane within its group, first lane of the group
+  const uint32_t gx = (p.W + 31u) / 32u, gy = (p.rows + 7u) / 8u;
+  const uint32_t slots = gx * gy * 4u;
+  const uint32_t slot = (blockIdx.x * 4u + wave) * T + lane / G;
+  const bool live = slot < slots;                                   // (group-uniform)
+  const uint32_t sl = live ? slot : 0u;
+  const uint32_t x0 = ((sl / 4u) % gx) * 32u + (sl % 4u) * 8u, y0 = ((sl / 4u) / gx) * 8u;
+  const bool in_image = live && x0 < p.W;                           // a slot right of the image has no pixel: empty list
+
+  const FocalBounds b = group_focal_bounds<FMA, G, SL>(p, x0, y0, in_image, gl, gbase);
+  const TileFamily fam = make_family<SL>(p, b);
+
+  // ---- classification, lane = triangle, G triangles per step ---------------------------------------------------------
+  uint32_t* const saved = p.tile_lists + static_cast<size_t>(sl) * (1u + p.bin_list);
+  const uint32_t n = p.n_tris;
+  uint32_t count = 0;
+  const float NEG = -__builtin_inff();
+  bool haveA = false;
+  float Q = NEG, M1 = NEG, M2 = NEG;
+  uint32_t A = 0, I1 = 0xFFFFFFFFu;
+  for (uint32_t base = 0; base < n; base += G) {                    // (wave-uniform trip count)
+    const uint32_t tri = base + gl;
+    const bool valid = in_image && tri < n;
+    const uint32_t ti = tri < n ? tri : n - 1u;
+    const float4 A0 = p.tri_a[2u * ti], A1 = p.tri_a[2u * ti + 1u];
+    const float bz = p.tri_b[ti];
+    bool keep = valid, sure = false;
+    float q[2] = {0.0f, 0.0f};
+    if (fam.usable) {                                               // (per lane: group-uniform)
+      const bool miss = tile_misses_triangle<false, true, SL>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z}, nullptr, &sure, q);
+      keep = valid && !miss;
+    } else {
+      sure = false;
+    }
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+    const unsigned long long gm = G == 64 ? m : ((m >> gbase) & 0xFFFFFFFFull);
+    const uint32_t pos = count + static_cast<uint32_t>(__builtin_popcountll(gm & ((1ull << gl) - 1ull)));
+    if (keep) saved[1u + pos] = tri;                                // ascending order
+    count += static_cast<uint32_t>(__builtin_popcountll(gm));
+    // running winner: the certainly-hit candidate with the largest lower bound of q, first in scan order on ties
+    const bool cand = keep && sure && fam.usable;
+    const float Qs = group_max<G>(cand ? q[0] : NEG);
+    const unsigned long long bm = __builtin_amdgcn_ballot_w64(cand && q[0] == Qs);
+    const unsigned long long gbm = G == 64 ? bm : ((bm >> gbase) & 0xFFFFFFFFull);
+    if (gbm != 0ull && (!haveA || Qs > Q)) { haveA = true; Q = Qs; A = base + static_cast<uint32_t>(__builtin_ctzll(gbm)); }
+    // the two largest upper bounds of q over the kept triangles (a NaN bound is no bound)
+    const float qh = keep ? ((q[1] == q[1]) ? q[1] : __builtin_inff()) : NEG;
+    const float m1s = group_max<G>(qh);
+    const unsigned long long tm = __builtin_amdgcn_ballot_w64(keep && qh == m1s);
+    const unsigned long long gtm = G == 64 ? tm : ((tm >> gbase) & 0xFFFFFFFFull);
+    const uint32_t l1 = gtm != 0ull ? static_cast<uint32_t>(__builtin_ctzll(gtm)) : 0xFFFFFFFFu;
+    const float m2s = group_max<G>((keep && gl != l1) ? qh : NEG);
+    if (gtm != 0ull) {
+      if (m1s > M1) { M2 = fmaxf(M1, m2s); M1 = m1s; I1 = base + l1; }
+      else { M2 = fmaxf(M2, m1s); }
+    }
+  }
+  bool sure_one = false;
+  if (haveA) {
+    const float R = (I1 == A) ? M2 : M1;                            // the largest upper bound among the OTHER kept triangles
+    sure_one = count <= 1u || (R < Q - 1e-4f * (__builtin_fabsf(R) + __builtin_fabsf(Q)));
+  }
+  if (live && gl == 0u) saved[0] = count | (A << 10) | (sure_one ? 0x80000000u : 0u);
+}
+
+// ------------------------------------------------------------------------------------
 // ------------------------------------------------------------------------------------
 // The trace kernel.  grid = (ceil(W/32), ceil(rows/8)), block = 256 threads.
 // Dynamic LDS: BIN ? 4 waves * bin_list * 40 bytes (104 with the per-sample forms, PRE) + block_list * 4
@@ -720,14 +892,19 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   rng.v4 = p.rng[5 * static_cast<size_t>(p.npix) + pix];
 
 
-  // A launch that loads its tile's stored list knows the certain-winner verdict before anything else: such a tile needs
-  // no pinhole ray either (its samples keep their RNG draws and additions only).
+  // Small scenes (ONEPASS): the tile's candidate list and its certain-winner verdict were built ahead of this launch by
+  // tile_lists_kernel (p.tile_lists; null only for a scene without triangles), so the wave knows the verdict before
+  // anything else: a tile with a certain winner needs no pinhole ray either (its samples keep their RNG draws and
+  // additions only).
   const bool sure_ok = BIN && ONEPASS && (p.flags & (TRACE_NEAREST_HIT | TRACE_NO_SURE_HIT)) == 0u && p.n_spheres == 0u && p.tri_n == nullptr;
   bool loaded_sure = false;
+  uint32_t list_word = 0u;                                          // count | winner << 10 | certain << 31
   if constexpr (BIN && ONEPASS) {
-    if ((p.flags & TRACE_LISTS_LOAD) != 0u && sure_ok) {
+    if (p.tile_lists != nullptr) {
       const size_t slot0 = (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 4u + wave;
-      loaded_sure = (static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(p.tile_lists[slot0 * (1u + p.bin_list)]))) >> 31) != 0u;
+      // wave-uniform by construction; readfirstlane tells the compiler (scalar loop control below)
+      list_word = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(p.tile_lists[slot0 * (1u + p.bin_list)])));
+      loaded_sure = sure_ok && (list_word >> 31) != 0u;
     }
   }
   V3 po = {0.0f, 0.0f, 0.0f}, pd = {0.0f, 0.0f, 0.0f}, focal = {0.0f, 0.0f, 0.0f};
@@ -780,9 +957,6 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   // (wave-uniform): the sample loop then needs neither rays nor tests (tile_misses_triangle<.., SURE>)
   bool sure_hit_tile = false;
   uint32_t sure_winner = 0;         // triangle index of the certain winner
-  bool lane_keep = false, lane_sure = false;      // this lane's verdicts of a one-step classification (lane = triangle)
-  float lane_q[2] = {0.0f, 0.0f};
-  uint32_t lane_tri = 0, class_steps = 0;
   // Block-level pre-cull (scenes larger than the per-wave list): the 256 threads classify every
   // triangle ONCE against the union of the block's four tile families and keep the survivors'
   // indices, in ascending order, in LDS; each wave then only refines that short list against its
@@ -804,20 +978,15 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
     }
   }
   const uint32_t n_src = src_count;  // triangles the block-level pre-cull walks over
-  // a launch that loads its tiles' stored candidate lists needs no ray family at all
-  const bool lists_loaded = ONEPASS && (p.flags & TRACE_LISTS_LOAD) != 0u;   // wave-uniform
-  if constexpr (BIN) {
+  // (small-scene kernels load their tiles' lists and need no ray family at all)
+  if constexpr (BIN && ONEPASS) fam.usable = false;
+  if constexpr (BIN && !ONEPASS) {
     tl_mark(8);                                                    // loads issued, pinhole + focal point done
-    FocalBounds wb;
-    wb.ok = false; wb.any = false;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { wb.lo[i] = 0.0f; wb.hi[i] = 0.0f; }
-    if (!lists_loaded) wb = focal_bounds(p, focal, inside);
+    const FocalBounds wb = focal_bounds(p, focal, inside);
     tl_mark(9);
-    if (!lists_loaded) fam = make_family(p, wb);
-    else fam.usable = false;
+    fam = make_family(p, wb);
     tl_mark(10);
-    if constexpr (!ONEPASS) {
+    {
       if (Lb != 0u) {
         const FocalBounds bb = block_focal_union(wb, bbox, wave, lane);
         const TileFamily bfam = make_family(p, bb);
@@ -875,10 +1044,6 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
         if constexpr (PRETEST && WF) {
           if (pretest) keep = valid && !tile_misses_triangle<true>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z}, forms);
           else keep = valid && !tile_misses_triangle(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z});
-        } else if constexpr (ONEPASS) {
-          keep = valid && !tile_misses_triangle<false, true>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z}, nullptr,
-                                                             &lane_sure, lane_q);
-          lane_keep = keep; lane_tri = tri; class_steps += 1u;
         } else {
           keep = valid && !tile_misses_triangle(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z});
         }
@@ -912,22 +1077,17 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
     return base < src_count ? base : src_count;
   };
 
-  // ONEPASS: the scene has no more triangles than the list holds (host-checked), so one
-  // classification before any ray exists is enough; keeping it out of the sample loop saves
-  // ~17 VGPRs (K = 2: 98 -> 96 with 5 waves/SIMD; measured C3 202 -> 192 us).
-  // Accumulating launches (same camera, scene and frame: host-checked) reuse the tile's
-  // candidate list that the first of them stored in HBM instead of re-classifying: the list
-  // depends on the tile's ray family only, not on the samples.
+  // ONEPASS: the scene has no more triangles than the list holds (host-checked).  The tile's list -- a function of the
+  // tile's ray family only, not of the samples -- comes from tile_lists_kernel: the wave gathers the records of the listed
+  // triangles into its LDS slot; a tile with a certain winner needs no records at all.
   if constexpr (BIN && ONEPASS) {
     const size_t slot = (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 4u + wave;
-    uint32_t* const saved = p.tile_lists + slot * (1u + L);
-    if (p.flags & TRACE_LISTS_LOAD) {
-      // wave-uniform by construction; readfirstlane tells the compiler (scalar loop control below)
-      const uint32_t word = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(saved[0])));
-      const uint32_t count = word & 0x3FFu;                          // bit 31: the tile has a certain winner, bits 10..19: its triangle
-      sure_hit_tile = sure_ok && (word >> 31) != 0u;
-      sure_winner = (word >> 10) & 0x3FFu;
-      for (uint32_t base = 0; base < (sure_hit_tile ? 0u : count); base += 64u) {   // (a certain winner needs no records)
+    const uint32_t count = list_word & 0x3FFu;                         // bit 31: the tile has a certain winner, bits 10..19: its triangle
+    sure_hit_tile = loaded_sure;
+    sure_winner = (list_word >> 10) & 0x3FFu;
+    if (p.tile_lists != nullptr) {
+      const uint32_t* const saved = p.tile_lists + slot * (1u + L);
+      for (uint32_t base = 0; base < (sure_hit_tile ? 0u : count); base += 64u) {
         const uint32_t e = base + lane;
         if (e < count) {
           const uint32_t tri = saved[1u + e];
@@ -937,35 +1097,11 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
           cI[e] = static_cast<int>(tri);
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      list_count = count;
-    } else {
-      (void)classify(0u, std::false_type{});
-      // Certain winner (scenes classified in one step, lane = triangle): the certainly-hit candidate with the largest
-      // lower bound of q, if every other candidate's upper bound stays below it.
-      bool sure_one = false;
-      if (class_steps == 1u && fam.usable) {
-        const float NEG = -__builtin_inff();
-        const bool cand = lane_keep && lane_sure;
-        const float Q = uniform(wave_max(cand ? lane_q[0] : NEG));
-        const unsigned long long best = __builtin_amdgcn_ballot_w64(cand && lane_q[0] == Q);
-        if (best != 0ull) {
-          const uint32_t A = static_cast<uint32_t>(__builtin_ctzll(best));
-          const bool other = lane_keep && lane != A;
-          const float qhi = (lane_q[1] == lane_q[1]) ? lane_q[1] : __builtin_inff();     // a NaN bound is no bound (fmax would drop it)
-          const float R = uniform(wave_max(other ? qhi : NEG));
-          const bool alone = __builtin_amdgcn_ballot_w64(other) == 0ull;
-          sure_one = alone || (R < Q - 1e-4f * (__builtin_fabsf(R) + __builtin_fabsf(Q)));
-          sure_winner = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(lane_tri), static_cast<int>(A)));
-        }
-      }
-      sure_hit_tile = sure_ok && sure_one;                             // (sure_one is independent of the launch's flags: stored as such)
-      if (p.flags & TRACE_LISTS_STORE) {
-        if (lane == 0u) saved[0] = list_count | (sure_winner << 10) | (sure_one ? 0x80000000u : 0u);
-        for (uint32_t e = lane; e < list_count; e += 64u) saved[1u + e] = static_cast<uint32_t>(cI[e]);
-      }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // this wave's ds_writes before its ds_reads
+    __builtin_amdgcn_wave_barrier();
+    list_count = count;
+    if constexpr (STATS) { st_bin[0] += count; st_bin[1] += 1; }
     list_complete = true;
   }
   // Large scenes: the first classification also runs BEFORE any ray exists (few live registers, and

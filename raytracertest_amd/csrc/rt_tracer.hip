@@ -402,7 +402,8 @@ struct rt_tracer {
     p.image_host = host_image;
     p.flags = flags | mode_flags(p);
     p.image = d_image;
-    const uint32_t list_flags = decide_tile_lists(p, (flags & rtk::TRACE_ZERO_ACC) != 0u);
+    bool have_lists = false;
+    const bool build_lists = prepare_tile_lists(p, (flags & rtk::TRACE_ZERO_ACC) != 0u, have_lists);
     last_k = K; last_chunk = p.chunk;
     last_lds = rtk::trace_lds_bytes(p, bin);
     // Event pairs bracket every `event_stride`-th launch (and every launch the caller waits for):
@@ -419,9 +420,10 @@ struct rt_tracer {
     if (timed) { e = take_events(); e.launches = 1; e.split = r0 != 0u; }
     if (r0 == 0u) {
       (void)main_stream();                                               // a launch on one stream orders behind both
-      attach_tile_lists(p, 0, list_flags);
+      attach_tile_lists(p, have_lists);
       if (timed) HIP_CHECK(hipEventRecord(e.a, stream));
-      attach_macro_lists(p, 0, stream);                                  // part of the launch: timed with it
+      if (build_lists) HIP_CHECK(rtk::launch_tile_lists(p, fma, stream)); // part of the launch: timed with it
+      attach_macro_lists(p, 0, stream);                                  // (likewise)
       HIP_CHECK(rtk::launch_trace(p, fma, filter, bin, K, stream));
       if (timed) HIP_CHECK(hipEventRecord(e.b, stream));
     } else {
@@ -430,7 +432,8 @@ struct rt_tracer {
       hipStream_t st[2] = {stream, stream_b};
       if (timed) HIP_CHECK(hipEventRecord(e.a, stream));                 // the sampled duration is the upper half-frame kernel's
       for (int h = 0; h < 2; ++h) {
-        attach_tile_lists(half[h], h, list_flags);
+        attach_tile_lists(half[h], have_lists);
+        if (build_lists) HIP_CHECK(rtk::launch_tile_lists(half[h], fma, st[h]));   // each half builds the lists of its own rows
         attach_macro_lists(half[h], h, st[h]);
         HIP_CHECK(rtk::launch_trace(half[h], fma, filter, bin, K, st[h]));
       }
@@ -545,20 +548,22 @@ struct rt_tracer {
   bool list_key_valid = false;
   uint32_t scene_generation = 0;
 
-  // Decides once per launch whether its tiles load, store or ignore stored candidate lists (returns the
-  // TRACE_LISTS_* flag or 0) and makes sure the buffer holds the whole band's lists.
-  uint32_t decide_tile_lists(const rtk::TraceParams& p, bool first_launch_of_trace) {
-    // reuse_across_traces == false (bench.py's headline): the launch that clears the accumulators always
-    // classifies on its own and stores nothing, so a one-launch Trace neither pays for nor profits from the cache
-    if (first_launch_of_trace && !reuse_across_traces) return 0u;
-    if (!bin || p.n_tris == 0u || p.n_tris > p.bin_list || getenv("RT_MI355X_NO_LIST_REUSE")) return 0u;
+  // Small scenes (no more triangles than the per-wave list holds): the tiles' candidate lists + certain-winner verdicts are
+  // built by tile_lists_kernel ahead of the trace launch that needs them.  Decides once per launch whether the lists have to
+  // be (re)built first -- camera snapshot, scene, frame, list length or arithmetic mode changed; or this is the first launch
+  // of a Trace and the lists are not kept across Traces (rt_tracer_set_list_reuse(t, 0): bench.py's headline, every step
+  // builds its own) -- and makes sure the buffer holds the whole band's lists.  have = the scene uses lists at all.
+  bool prepare_tile_lists(const rtk::TraceParams& p, bool first_launch_of_trace, bool& have) {
+    have = false;
+    if (!bin || p.n_tris == 0u || p.n_tris > p.bin_list) return false;
+    have = true;
     const size_t tiles = static_cast<size_t>((W + 31u) / 32u) * ((rows + 7u) / 8u + 1u) * 4u;   // (+1: a split adds a partial block row)
     const size_t words = tiles * (1u + p.bin_list);
     if (words > tile_lists_words) {
       if (d_tile_lists) (void)hipFree(d_tile_lists);
       d_tile_lists = nullptr; tile_lists_words = 0; list_key_valid = false;
       HIP_CHECK(hipMalloc(&d_tile_lists, words * sizeof(uint32_t)));
-      HIP_CHECK(hipMemsetAsync(d_tile_lists, 0, words * sizeof(uint32_t), main_stream()));   // count 0 everywhere until a launch stores
+      HIP_CHECK(hipMemsetAsync(d_tile_lists, 0, words * sizeof(uint32_t), main_stream()));   // count 0 everywhere until a launch builds
       tile_lists_words = words;
     }
     ListKey k;
@@ -567,21 +572,22 @@ struct rt_tracer {
     k.half_height = p.half_height; k.aspect = p.aspect; k.focal = p.focal; k.aperture = p.aperture;
     k.W = p.W; k.H = p.H; k.row0 = p.row0; k.rows = p.rows; k.bin_list = p.bin_list; k.n_tris = p.n_tris;
     k.scene_generation = scene_generation; k.fma = fma;
-    const bool same = list_key_valid && memcmp(&k, &list_key, sizeof k) == 0;
-    if (same) return rtk::TRACE_LISTS_LOAD;
+    static const bool never = [] { const char* e = getenv("RT_MI355X_NO_LIST_REUSE"); return e && e[0] == '1'; }();   // A/B: every launch builds
+    const bool same = list_key_valid && memcmp(&k, &list_key, sizeof k) == 0 && !never &&
+                      !(first_launch_of_trace && !reuse_across_traces);
+    if (same) return false;
     list_key = k;
     list_key_valid = true;
-    return rtk::TRACE_LISTS_STORE;
+    return true;
   }
 
   // Points one (half-)launch at its slots of the list buffer: a lower half starts behind the upper half's
   // block rows (the split row is a multiple of 8).
-  void attach_tile_lists(rtk::TraceParams& p, int /*half*/, uint32_t list_flags) {
+  void attach_tile_lists(rtk::TraceParams& p, bool have) {
     p.tile_lists = nullptr;
-    if (list_flags == 0u) return;
+    if (!have) return;
     const size_t slot_base = static_cast<size_t>((W + 31u) / 32u) * ((p.row0 - row0) / 8u) * 4u;
     p.tile_lists = d_tile_lists + slot_base * (1u + p.bin_list);
-    p.flags |= list_flags;
   }
 
   // Macro level of the classification (scenes that do not fit the per-wave list): sizes the
@@ -1257,6 +1263,10 @@ int rt_tracer_trace_stats(rt_tracer* t, uint32_t samples, uint64_t out[16]) {
     rtk::TraceParams p = t->params(samples);
     p.stats = counters.as<unsigned long long>();
     p.flags = t->mode_flags(p);
+    bool have_lists = false;
+    const bool build_lists = t->prepare_tile_lists(p, true, have_lists);
+    t->attach_tile_lists(p, have_lists);
+    if (build_lists) HIP_CHECK(rtk::launch_tile_lists(p, t->fma, t->main_stream()));
     t->attach_macro_lists(p, 0, t->main_stream());
     HIP_CHECK(rtk::launch_trace(p, t->fma, t->filter, t->bin, t->pick_k(samples), t->main_stream()));
     HIP_CHECK(hipStreamSynchronize(t->main_stream()));
@@ -1562,6 +1572,10 @@ extern "C" int rt_dbg_trace_timeline(rt_tracer* t, uint32_t samples, unsigned lo
     p.flags = rtk::TRACE_ZERO_ACC | rtk::TRACE_EMIT_IMAGE | t->mode_flags(p);
     p.image = t->d_image;
     p.timeline = buf.as<unsigned long long>();
+    bool have_lists = false;
+    const bool build_lists = t->prepare_tile_lists(p, true, have_lists);
+    t->attach_tile_lists(p, have_lists);
+    if (build_lists) HIP_CHECK(rtk::launch_tile_lists(p, t->fma, t->main_stream()));
     t->attach_macro_lists(p, 0, t->main_stream());
     HIP_CHECK(rtk::launch_trace(p, t->fma, t->filter, t->bin, t->pick_k(samples), t->main_stream()));
     HIP_CHECK(hipStreamSynchronize(t->main_stream()));
@@ -1579,7 +1593,7 @@ int rt_dbg_read_tile_lists(rt_tracer* t, uint32_t* dst, size_t capacity_words, u
     t->cancel_and_join();
     t->use_device();
     HIP_CHECK(hipStreamSynchronize(t->main_stream()));
-    if (!t->d_tile_lists || !t->list_key_valid) throw HipFail{"no stored tile lists (small scenes store them on the second launch of a Trace)"};
+    if (!t->d_tile_lists || !t->list_key_valid) throw HipFail{"no tile lists (small scenes build them ahead of their first trace launch)"};
     const size_t n = t->tile_lists_words < capacity_words ? t->tile_lists_words : capacity_words;
     HIP_CHECK(hipMemcpy(dst, t->d_tile_lists, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (words_per_tile) *words_per_tile = 1u + t->list_key.bin_list;

@@ -193,8 +193,27 @@ def cover_config(rng):
     cam = dict(angles=(float(rng.uniform(-3.2, 3.2)), float(rng.uniform(-3.2, 3.2))), fov=float(rng.uniform(5, 120)),
                focal=float(scale * 10.0 ** rng.uniform(-1, 1)),
                aperture=float(scale * rng.choice([0.0, 1e-4, 1e-3, 0.01, 0.03])))
-    n = int(rng.choice([3, 8, 20, 40, 64]))
+    n = int(rng.choice([3, 8, 20, 40, 62]))
     tris = adversarial_triangles(rng, cam, W, H, n, scale, KINDS_COVER)
+    if rng.uniform() < 0.75:
+        # a backdrop: one or two big camera-facing triangles beyond (nearly) everything else -- the reference keeps the
+        # FARTHEST hit (Kernels.cuh:84), so this is the winner of every tile it covers, like the walls of the Cornell box
+        o, dcen, _ = family_ray(cam, W, H, W / 2.0 - 0.5, H / 2.0 - 0.5, (0.0, 0.0))
+        far = float(np.abs(tris).max()) * float(rng.choice([1.5, 3.0, 30.0])) + scale
+        half = far * np.tan(np.radians(min(cam["fov"], 150.0)) / 2.0) * max(W / float(H), 1.0) + cam["aperture"]
+        a = _perp(rng, dcen)
+        b = np.cross(dcen, a)
+        back = []
+        for k in range(int(rng.integers(1, 3))):
+            T = far * (1.0 + 0.37 * k)
+            cen = o + dcen * T
+            R = half * (1.0 + 0.37 * k) * float(rng.choice([0.6, 2.5, 4.0]))      # 0.6: covers only the middle of the frame
+            tri = np.array([cen + a * 2.0 * R, cen + (-a + 1.7320508 * b) * R, cen + (-a - 1.7320508 * b) * R])
+            e1, e2 = tri[1] - tri[0], tri[2] - tri[0]
+            if e1 @ np.cross(dcen, e2) < 0.0:                                    # det > 0: the camera-facing winding
+                tri = tri[[0, 2, 1]]
+            back.append(tri)
+        tris = np.concatenate([tris, np.nan_to_num(np.array(back), posinf=3e38, neginf=-3e38).astype(np.float32)])
     return dict(scale=scale, W=W, H=H, cam=cam, tris=tris, mode=int(rng.integers(0, 2)), spp=int(rng.integers(1, 9)),
                 iters=int(rng.integers(1, 3)), seed=int(rng.integers(1, 1 << 30)), nearest=False)
 

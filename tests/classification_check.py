@@ -148,7 +148,7 @@ def _needed(vmin, vmax, lo1, hi1, lo0, hi0):
     return np.maximum(up, dn)
 
 
-SURE_MAX_TRIS = 64      # the trace kernel decides certain winners for scenes classified in one step (lane = triangle)
+SURE_MAX_TRIS = 256     # every small scene (tile_lists_kernel carries the verdict across classification steps)
 
 
 def check_region(tag, probe, nohit, rays, recs, hdrs, forms=False, tile_word=None, stored_list=None):
@@ -158,7 +158,8 @@ def check_region(tag, probe, nohit, rays, recs, hdrs, forms=False, tile_word=Non
     n = probe.shape[0]
     t.regions, t.pairs, t.rays = 1, n, rays * n
     r1, h1 = recs[1000].astype(np.float64), hdrs[1000]
-    usable = h1[8] != 0.0
+    usable = (int(h1[8]) & 1) != 0
+    assert int(h1[8]) & 2, "%s: the two focal-bound paths (list builder / trace wave) disagree" % tag
     flags1 = recs[1000][:, 0].astype(np.int32)
     keep1 = (flags1 & 1) != 0
     sure1 = (flags1 & 2) != 0
@@ -177,7 +178,7 @@ def check_region(tag, probe, nohit, rays, recs, hdrs, forms=False, tile_word=Non
         b["drop_win"] = int(((~keep) & (wins > 0)).sum())
         b["sure_miss"] = int((sure & (hits < probe["rays"])).sum())
         if not forms:
-            win = certain_winner(recs[s], hdrs[s][8] != 0.0)
+            win = certain_winner(recs[s], (int(hdrs[s][8]) & 1) != 0)
             if win is not None and wins[win] != rays:
                 b["tile_winner"] = 1
         if (b["drop_hit"] or b["sure_miss"] or b["tile_winner"]) and s == 1000:
