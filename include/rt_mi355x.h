@@ -300,11 +300,13 @@ int rt_dbg_focal_boxes(rt_tracer* t, float curv_scale, float* boxes, size_t boxe
 /* The conservative classification verdict by verdict (tests/test_gpu_classification.py, CLASSIFICATION.md): for each of
  * n_regions regions of the band -- level 0: the 8x8 wave tile at pixel (regions[2i], regions[2i+1]) (x a multiple of 8, band-local
  * row a multiple of 8), bounded exactly as a trace wave bounds it; level 1: the 32x8 block (x a multiple of 32), the union of
- * its four wave tiles; level 2: the 128x64 macro tile -- and for EVERY triangle of the scene, what tile_misses_triangle decides
+ * its four wave tiles; level 2: the 128x64 macro tile; level 3: the 32x16 region of the small scenes' two-level list builder
+ * (x a multiple of 32, row a multiple of 16), the union of its eight tiles' boxes -- and for EVERY triangle of the scene, what tile_misses_triangle decides
  * and the interval ends it decides from, with every rounding allowance multiplied by slack_milli / 1000 (1000 = the product;
  * 300, 100, 30, 10, 0 exist so that the margin can be measured in the shipped library).
  *   out[region] = 16 floats: focal box lo[3], hi[3], lmin, lmax of |F - o|, usable (1) + 2 when the focal bounds of the list
- *   builder (group_focal_bounds) and of a large-scene trace wave (focal_bounds) agree bit for bit, lens radius A, orad[3], fc[3], followed by
+ *   builder and of a large-scene trace wave (focal_bounds) agree bit for bit, + 4 when the host vouches for the corner bound (the
+ *   two-level list builder is in use; level 3 is meaningless otherwise), lens radius A, orad[3], fc[3], followed by
  *   n_tris records.  forms == 0 (small-scene instantiation), 12 floats: flags (1 = kept, 2 = certainly hit by every ray of the
  *   family), det_lo, det_hi, U_lo, U_hi, V_lo, V_hi (bounds of det', U', V' = the reference's det, U = dot(tv, pv), V = dot(dir, qv)
  *   of Kernels.cuh:40,50,57 times |F - o|), q_lo, q_hi (bounds of t / |F - o|, t of Kernels.cuh:63), Nt_lo, Nt_hi, 0.

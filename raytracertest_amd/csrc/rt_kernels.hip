@@ -6,6 +6,8 @@
 //                         (rt_trace.hpp; RayTracer/Kernels.cuh:29-147, ThinLensCamera.cuh:30-52,111-130)
 //   convert_kernel     <- rt::ConverterKernel              (RayTracer/Kernels.cuh:149-169)
 //   dbg_* kernels      <- single-function harnesses used by the parity tests
+#include <stdlib.h>
+
 #include "rt_trace.hpp"
 
 namespace rtk {
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256) void dbg_focal_boxes_kernel(const TraceParams 
 // (block_focal_union, the trace kernel's block-level pre-cull); level 2: the macro tile of p.macro_w x p.macro_h pixels
 // at (x0, y0) (macro_focal_bounds, macro_bin_kernel) -- and for EVERY triangle of the scene what
 // tile_misses_triangle decides and the interval ends it decides from, with every rounding allowance scaled by SL::scale.
-//   out[region] = 16 header floats: focal lo[3], hi[3], lmin, lmax, usable (+ 2: the two focal-bound paths agree), A, orad[3], fc[3]
+//   out[region] = 16 header floats: focal lo[3], hi[3], lmin, lmax, usable (+ 2: the focal-bound paths agree, + 4: p.tile_curv > 0, the two-level list builder is in use), A, orad[3], fc[3]
 //               + n_tris x stride floats: flags (1 keep | 2 certainly hit), det_lo, det_hi, U_lo, U_hi, V_lo, V_hi,
 //                 q_lo, q_hi, Nt_lo, Nt_hi, 0 (stride 12; the small-scene instantiation <false, SURE>), or, FORMS:
 //                 flags (1 keep), the same six ends, 5 x 0, then the 18 numbers of the per-sample forms with the gradients
@@ -178,6 +180,9 @@ __global__ __launch_bounds__(256) void dbg_classify_kernel(const TraceParams p, 
   bool paths_agree = true;           // level 0: focal_bounds (trace waves of large scenes) == group_focal_bounds (list builder)
   if (level == 2u) {
     bb = macro_focal_bounds<FMA>(p, x0, y0, s_box);
+  } else if (level == 3u) {                          // the 32x16 region of the two-level list builder: the union of its tiles' boxes
+    FocalBounds tb;
+    region_focal_bounds<FMA, SL>(p, x0 / 32u, y0 / 16u, lane, tb, bb);
   } else {
     const uint32_t px = x0 + wave * 8u + (lane & 7u), ly = y0 + (lane >> 3);
     const bool inside = px < p.W && ly < p.rows;
@@ -192,16 +197,29 @@ __global__ __launch_bounds__(256) void dbg_classify_kernel(const TraceParams p, 
       // the wave tile at (x0, y0): the bounds tile_lists_kernel builds the tile's list from (small scenes) -- identical to
       // what the trace wave of a large scene computes for its tile (focal_bounds, wave 0 above: s_box[0]); both are exported
       // paths of the same arithmetic, the harness takes the list builder's
-      bb = group_focal_bounds<FMA, 64, SL>(p, x0, y0, x0 < p.W, lane, 0u);
-      paths_agree = s_box[0][0] == bb.lo[0] && s_box[0][1] == bb.lo[1] && s_box[0][2] == bb.lo[2] && s_box[0][3] == bb.hi[0] &&
-                    s_box[0][4] == bb.hi[1] && s_box[0][5] == bb.hi[2] && (s_box[0][6] != 0.0f) == bb.ok && (s_box[0][7] != 0.0f) == bb.any;
+      const bool full = x0 + 8u <= p.W && y0 + 8u <= p.rows;
+      if (p.tile_curv > 0.0f) {                      // what region_lists_kernel gives this tile (clamped corners for edge tiles)
+        FocalBounds tb, rb;
+        region_focal_bounds<FMA, SL>(p, x0 / 32u, y0 / 16u, lane, tb, rb);
+        const int src = static_cast<int>(4u * ((((y0 / 8u) & 1u) << 2) | ((x0 / 8u) & 3u)));
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { bb.lo[i] = __shfl(tb.lo[i], src, 64); bb.hi[i] = __shfl(tb.hi[i], src, 64); }
+        bb.ok = ((__builtin_amdgcn_ballot_w64(tb.ok) >> src) & 1ull) != 0ull;
+        bb.any = ((__builtin_amdgcn_ballot_w64(tb.any) >> src) & 1ull) != 0ull;
+      } else {
+        bb = group_focal_bounds<FMA, 64, SL>(p, x0, y0, x0 < p.W, lane, 0u);
+      }
+      // full tiles: every path is the same four corner pixels (or the same 64): bit-identical boxes
+      paths_agree = !full || (s_box[0][0] == bb.lo[0] && s_box[0][1] == bb.lo[1] && s_box[0][2] == bb.lo[2] && s_box[0][3] == bb.hi[0] &&
+                              s_box[0][4] == bb.hi[1] && s_box[0][5] == bb.hi[2] && (s_box[0][6] != 0.0f) == bb.ok && (s_box[0][7] != 0.0f) == bb.any);
     }
   }
   const TileFamily fam = make_family<SL>(p, bb);
   if (threadIdx.x == 0u) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) { o[i] = bb.lo[i]; o[3 + i] = bb.hi[i]; o[10 + i] = fam.orad[i]; o[13 + i] = fam.fc[i]; }
-    o[6] = fam.lmin; o[7] = fam.lmax; o[8] = (fam.usable ? 1.0f : 0.0f) + (paths_agree ? 2.0f : 0.0f); o[9] = fam.A;
+    o[6] = fam.lmin; o[7] = fam.lmax; o[9] = fam.A;
+    o[8] = (fam.usable ? 1.0f : 0.0f) + (paths_agree ? 2.0f : 0.0f) + (p.tile_curv > 0.0f ? 4.0f : 0.0f);
   }
   for (uint32_t tri = threadIdx.x; tri < p.n_tris; tri += 256u) {
     const float4 A0 = p.tri_a[2u * tri], A1 = p.tri_a[2u * tri + 1u];
@@ -397,6 +415,13 @@ hipError_t launch_macro_bin(const TraceParams& p, bool fma, hipStream_t st) {
 
 hipError_t launch_tile_lists(const TraceParams& p, bool fma, hipStream_t st) {
   if (p.tile_lists == nullptr || p.rows == 0u || p.W == 0u) return hipSuccess;
+  static const bool flat = [] { const char* e = getenv("RT_MI355X_LISTS_FLAT"); return e && e[0] == '1'; }();   // A/B: one-level build
+  if (p.tile_curv > 0.0f && !flat) {                                 // two levels: region -> tiles
+    const dim3 grid(cdiv(cdiv(p.W, 32) * cdiv(cdiv(p.rows, 8), 2), 4u));
+    if (fma) hipLaunchKernelGGL((region_lists_kernel<true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((region_lists_kernel<false>), grid, dim3(256), 0, st, p);
+    return hipGetLastError();
+  }
   const uint32_t slots = cdiv(p.W, 32) * cdiv(p.rows, 8) * 4u;
   if (p.n_tris <= 32u) {                                             // two tiles per wave
     const dim3 grid(cdiv(slots, 8u));

@@ -118,6 +118,12 @@ struct Group {
         frame_free_valid[i] = false;
       }
     }
+    // The memsets above ran on the null stream, which the tracers' non-blocking streams are not ordered with: make sure they
+    // have landed before any trace kernel writes a tile into these buffers.
+    for (GatherRank& r : local) {
+      HIP_CHECK(hipSetDevice(r.device));
+      HIP_CHECK(hipDeviceSynchronize());
+    }
     next_b = 0; last_b = -1;
   }
 

@@ -691,18 +691,34 @@ __global__ __launch_bounds__(256) void macro_bin_kernel(TraceParams p) {
 // Per tile slot (grid order of the trace launch, 4 per 32x8 block): word 0 = count | winner << 10 | certain << 31,
 // then the kept triangle indices, ascending.  grid = ceil(slots / (4 * (64 / G))) blocks of 256 threads.
 // ------------------------------------------------------------------------------------
+// Max / min over the G lanes of a group, in every lane.  The list builder is latency-bound (one dependent chain per wave,
+// few waves per SIMD), unlike the VALU-issue-bound trace kernel: inside a row of 16 lanes the butterfly runs on DPP
+// (quad_perm [1,0,3,2], [2,3,0,1], row_ror:4, row_ror:8 -- VALU latency, no LDS round trip), only the steps across rows go
+// through ds_bpermute.  Every lane of the wave is active here.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+#define RT_ROW_REDUCE(OP, v)                 \
+  v = OP(v, dpp_f<0xB1>(v));                 \
+  v = OP(v, dpp_f<0x4E>(v));                 \
+  v = OP(v, dpp_f<0x124>(v));                \
+  v = OP(v, dpp_f<0x128>(v));
 template <int G>
 __device__ __forceinline__ float group_max(float v) {
+  RT_ROW_REDUCE(fmaxf, v)
 #pragma unroll
-  for (int off = G / 2; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  for (int off = G / 2; off >= 16; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
   return v;
 }
 template <int G>
 __device__ __forceinline__ float group_min(float v) {
+  RT_ROW_REDUCE(fminf, v)
 #pragma unroll
-  for (int off = G / 2; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+  for (int off = G / 2; off >= 16; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
   return v;
 }
+#undef RT_ROW_REDUCE
 
 // The focal bounds of the 8x8 tile at (x0, y0) of the band for the G lanes that own it (gl = lane within the group, gbase =
 // its first lane): full tiles take the four corner pixels' focal points -- computed exactly as the rays use them -- widened
@@ -770,7 +786,7 @@ __device__ __forceinline__ FocalBounds group_focal_bounds(const TraceParams& p, 
 }
 
 template <bool FMA, int G, class SL = SlackProduct>
-__global__ __launch_bounds__(256) void tile_lists_kernel(const TraceParams p) {
+__global__ __launch_bounds__(256, 5) void tile_lists_kernel(const TraceParams p) {
   static_assert(G == 32 || G == 64, "lanes per tile");
   constexpr uint32_t T = 64u / G;                                   // tiles per wave
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -821,6 +837,12 @@ __global__ __launch_bounds__(256) void tile_lists_kernel(const TraceParams p) {
     if (gbm != 0ull && (!haveA || Qs > Q)) { haveA = true; Q = Qs; A = base + static_cast<uint32_t>(__builtin_ctzll(gbm)); }
     // the two largest upper bounds of q over the kept triangles (a NaN bound is no bound)
     const float qh = keep ? ((q[1] == q[1]) ? q[1] : __builtin_inff()) : NEG;
+    if (n <= G) {                                                    // one step (wave-uniform): A is final, R directly
+      const uint32_t la = gbm != 0ull ? static_cast<uint32_t>(__builtin_ctzll(gbm)) : 0xFFFFFFFFu;
+      M1 = group_max<G>((keep && gl != la) ? qh : NEG);
+      I1 = 0xFFFFFFFEu;                                              // "not A": R = M1 below
+      break;
+    }
     const float m1s = group_max<G>(qh);
     const unsigned long long tm = __builtin_amdgcn_ballot_w64(keep && qh == m1s);
     const unsigned long long gtm = G == 64 ? tm : ((tm >> gbase) & 0xFFFFFFFFull);
@@ -837,6 +859,186 @@ __global__ __launch_bounds__(256) void tile_lists_kernel(const TraceParams p) {
     sure_one = count <= 1u || (R < Q - 1e-4f * (__builtin_fabsf(R) + __builtin_fabsf(Q)));
   }
   if (live && gl == 0u) saved[0] = count | (A << 10) | (sure_one ? 0x80000000u : 0u);
+}
+
+// ------------------------------------------------------------------------------------
+// The same lists, built in two levels (the default whenever the host vouches for the corner bound, p.tile_curv > 0).
+//
+// tile_lists_kernel above spends one full classification (~260 instructions on G lanes) per tile although a C3 tile keeps
+// 1.2 of the 32 triangles: 11 M wave-instructions per 1080p frame, latency-bound, a fifth of what the trace itself costs.
+// Here one wave owns a REGION of 4 x 2 tiles (32 x 16 pixels, two stacked trace blocks):
+//   1. one pinhole pass gives the focal points of all 32 tile-corner pixels (lane = tile * 4 + corner; a tile clipped by the
+//      image edge takes the corners of its in-image rectangle: cx, cy are monotone in the pixel index and the curvature term of
+//      a smaller rectangle is smaller, so the same allowance p.tile_curv bounds it); quad-wide DPP min/max give every tile its
+//      focal box, a row reduction their union = the region's box;
+//   2. level 1, lane = triangle: the whole scene against the REGION's family (a superset of every tile's family, so whatever
+//      it drops no ray of any of the tiles can hit); survivors, ascending, to a per-wave list in LDS (C3: ~3 of 32);
+//   3. level 2, lane = tile * 8 + candidate: 8 region candidates per pass against each of the 8 tiles' own families, with the
+//      certain-winner bounds; per-tile compaction (8-lane groups), the running winner / top-two bookkeeping of
+//      tile_lists_kernel, the list and its header word to the tile's slot.
+// ~130 instead of ~350 instructions per tile, a quarter of the waves.  A tile's list is a subset of what the one-level
+// build keeps (both are conservative: the image cannot tell them apart); rt_dbg_classify exports both levels' verdicts
+// (level 0: the tile, all triangles; level 3: the region) and tests/test_gpu_classification.py checks the lists the product
+// really stored against the reference's per-ray arithmetic.
+// grid = ceil(regions / 4) blocks of 256 threads, regions = ceil(W / 32) * ceil(ceil(rows / 8) / 2).
+// ------------------------------------------------------------------------------------
+template <class SL>
+__device__ __forceinline__ float tile_dev(const TraceParams& p) { return p.tile_curv + RT_SLK(4e-6f) * p.tile_round; }
+
+// lane -> (tile of the region, corner): the corner pixel of the tile's in-image rectangle, band-local; valid = tile in the band
+__device__ __forceinline__ void region_corner_pixel(const TraceParams& p, uint32_t rx, uint32_t ry, uint32_t tile, uint32_t corner,
+                                                    uint32_t& px, uint32_t& py, bool& valid) {
+  const uint32_t x0 = rx * 32u + (tile & 3u) * 8u, y0 = (ry * 2u + (tile >> 2)) * 8u;
+  valid = x0 < p.W && y0 < p.rows;
+  const uint32_t x1 = (x0 + 7u < p.W) ? x0 + 7u : p.W - 1u, y1 = (y0 + 7u < p.rows) ? y0 + 7u : p.rows - 1u;
+  px = valid ? ((corner & 1u) ? x1 : x0) : 0u;
+  py = valid ? ((corner & 2u) ? y1 : y0) : 0u;
+}
+
+// Focal boxes of the 8 tiles of region (rx, ry) -- in lanes 4 t .. 4 t + 3 of both half-waves -- and their union (every lane).
+template <bool FMA, class SL>
+__device__ __forceinline__ void region_focal_bounds(const TraceParams& p, uint32_t rx, uint32_t ry, uint32_t lane,
+                                                    FocalBounds& tile_b, FocalBounds& region_b) {
+  const uint32_t l32 = lane & 31u;
+  uint32_t px, py;
+  bool valid;
+  region_corner_pixel(p, rx, ry, l32 >> 2, l32 & 3u, px, py, valid);
+  V3 po, pd;
+  pinhole<FMA>(p, px, p.row0 + py, po, pd);
+  const V3 f = focal_point<FMA>(p, pd);
+  const float fl[3] = {f.x, f.y, f.z};
+  const float dev = tile_dev<SL>(p);
+  bool fin = true;
+  float rlo[3], rhi[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float lo = fl[i], hi = fl[i];
+    lo = fminf(lo, dpp_f<0xB1>(lo)); lo = fminf(lo, dpp_f<0x4E>(lo));          // the tile's four corners: quad-wide
+    hi = fmaxf(hi, dpp_f<0xB1>(hi)); hi = fmaxf(hi, dpp_f<0x4E>(hi));
+    tile_b.lo[i] = lo - dev;
+    tile_b.hi[i] = hi + dev;
+    fin = fin && (__builtin_fabsf(tile_b.lo[i]) <= FLT_MAX) && (__builtin_fabsf(tile_b.hi[i]) <= FLT_MAX) && (fl[i] == fl[i]);
+    rlo[i] = valid ? tile_b.lo[i] : FLT_MAX;
+    rhi[i] = valid ? tile_b.hi[i] : -FLT_MAX;
+  }
+  // (a NaN corner makes lo/hi of its quad NaN-free through fmin/fmax: the corners themselves are asked, quad-wide)
+  const unsigned long long badm = __builtin_amdgcn_ballot_w64(!fin);
+  const uint32_t quad_bad = (static_cast<uint32_t>(badm >> (lane & 28u)) & 0xFu);                 // lanes 0..31 mirror 32..63
+  tile_b.ok = quad_bad == 0u;
+  tile_b.any = valid;
+  const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
+  region_b.any = (vm & 0xFFFFFFFFull) != 0ull;
+  region_b.ok = ((badm & vm) & 0xFFFFFFFFull) == 0ull;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    region_b.lo[i] = group_min<32>(rlo[i]);
+    region_b.hi[i] = group_max<32>(rhi[i]);
+  }
+}
+
+// 8-lane groups: max in every lane of the group (quad_perm x 2, row_half_mirror)
+__device__ __forceinline__ float max8(float v) {
+  v = fmaxf(v, dpp_f<0xB1>(v));
+  v = fmaxf(v, dpp_f<0x4E>(v));
+  v = fmaxf(v, dpp_f<0x141>(v));
+  return v;
+}
+
+template <bool FMA, class SL = SlackProduct>
+__global__ __launch_bounds__(256, 5) void region_lists_kernel(const TraceParams p) {
+  __shared__ uint32_t s_cand[4][256];                               // per wave: the region's candidates, ascending
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t gx = (p.W + 31u) / 32u, gy = (p.rows + 7u) / 8u, gry = (gy + 1u) / 2u;
+  const uint32_t region = blockIdx.x * 4u + wave;
+  if (region >= gx * gry) return;                                   // wave-uniform
+  const uint32_t rx = region % gx, ry = region / gx;
+  FocalBounds tb, rb;
+  region_focal_bounds<FMA, SL>(p, rx, ry, lane, tb, rb);
+  const uint32_t n = p.n_tris;
+  uint32_t* const cand = s_cand[wave];
+
+  // ---- level 1: the scene against the region's family, lane = triangle ---------------------------------------------
+  uint32_t cnt = 0;
+  {
+    const TileFamily rf = make_family<SL>(p, rb);
+    for (uint32_t base = 0; base < n; base += 64u) {
+      const uint32_t tri = base + lane;
+      const bool valid = tri < n;
+      const uint32_t ti = valid ? tri : n - 1u;
+      const float4 A0 = p.tri_a[2u * ti], A1 = p.tri_a[2u * ti + 1u];
+      const float bz = p.tri_b[ti];
+      bool keep = valid;
+      if (rf.usable) keep = valid && !tile_misses_triangle<false, false, SL>(rf, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z});
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+      const uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+      if (keep) cand[pos] = tri;
+      cnt += static_cast<uint32_t>(__builtin_popcountll(m));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // this wave's ds_writes before its ds_reads
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // ---- level 2: 8 candidates x the 8 tiles, lane = tile * 8 + candidate slot ---------------------------------------------
+  const uint32_t t8 = lane >> 3, j = lane & 7u;
+  FocalBounds mine;                                                  // tile t8's box: from lane 4 * t8
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    mine.lo[i] = __shfl(tb.lo[i], static_cast<int>(4u * t8), 64);
+    mine.hi[i] = __shfl(tb.hi[i], static_cast<int>(4u * t8), 64);
+  }
+  const unsigned long long okm = __builtin_amdgcn_ballot_w64(tb.ok), anym = __builtin_amdgcn_ballot_w64(tb.any);
+  mine.ok = ((okm >> (4u * t8)) & 1ull) != 0ull;
+  mine.any = ((anym >> (4u * t8)) & 1ull) != 0ull;
+  const bool tile_valid = mine.any;                                  // the tile has pixels in the band
+  const TileFamily fam = make_family<SL>(p, mine);
+  const uint32_t tslot = ((ry * 2u + (t8 >> 2)) * gx + rx) * 4u + (t8 & 3u);
+  uint32_t* const saved = p.tile_lists + static_cast<size_t>(tile_valid ? tslot : 0u) * (1u + p.bin_list);
+  const bool slot_live = (ry * 2u + (t8 >> 2)) < gy;                 // (a slot right of the image exists and gets an empty list)
+  const float NEG = -__builtin_inff();
+  uint32_t count = 0;
+  bool haveA = false;
+  float Q = NEG, M1 = NEG, M2 = NEG;
+  uint32_t A = 0, I1 = 0xFFFFFFFFu;
+  const uint32_t gsh = lane & 56u;                                   // first lane of this 8-lane group
+  for (uint32_t c0 = 0; c0 < cnt; c0 += 8u) {                        // (wave-uniform trip count)
+    const bool has = tile_valid && c0 + j < cnt;
+    const uint32_t tri = cand[(c0 + j < cnt) ? c0 + j : 0u];
+    const float4 A0 = p.tri_a[2u * tri], A1 = p.tri_a[2u * tri + 1u];
+    const float bz = p.tri_b[tri];
+    bool keep = has, sure = false;
+    float q[2] = {0.0f, 0.0f};
+    if (fam.usable) {
+      const bool miss = tile_misses_triangle<false, true, SL>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z}, nullptr, &sure, q);
+      keep = has && !miss;
+    }
+    const uint32_t gm = static_cast<uint32_t>(__builtin_amdgcn_ballot_w64(keep) >> gsh) & 0xFFu;
+    const uint32_t pos = count + static_cast<uint32_t>(__builtin_popcount(gm & ((1u << j) - 1u)));
+    if (keep) saved[1u + pos] = tri;                                 // ascending: candidates and passes ascend
+    count += static_cast<uint32_t>(__builtin_popcount(gm));
+    const bool cd = keep && sure && fam.usable;
+    const float Qs = max8(cd ? q[0] : NEG);
+    const uint32_t gbm = static_cast<uint32_t>(__builtin_amdgcn_ballot_w64(cd && q[0] == Qs) >> gsh) & 0xFFu;
+    if (gbm != 0u && (!haveA || Qs > Q)) { haveA = true; Q = Qs; A = cand[c0 + static_cast<uint32_t>(__builtin_ctz(gbm))]; }
+    const float qh = keep ? ((q[1] == q[1]) ? q[1] : __builtin_inff()) : NEG;
+    const float m1s = max8(qh);
+    const uint32_t gtm = static_cast<uint32_t>(__builtin_amdgcn_ballot_w64(keep && qh == m1s) >> gsh) & 0xFFu;
+    const uint32_t l1 = gtm != 0u ? static_cast<uint32_t>(__builtin_ctz(gtm)) : 0xFFFFFFFFu;
+    const float m2s = max8((keep && j != l1) ? qh : NEG);
+    if (gtm != 0u) {
+      const uint32_t i1s = cand[c0 + l1];
+      if (m1s > M1) { M2 = fmaxf(M1, m2s); M1 = m1s; I1 = i1s; }
+      else { M2 = fmaxf(M2, m1s); }
+    }
+  }
+  bool sure_one = false;
+  if (haveA) {
+    const float R = (I1 == A) ? M2 : M1;                             // the largest upper bound among the OTHER kept triangles
+    sure_one = count <= 1u || (R < Q - 1e-4f * (__builtin_fabsf(R) + __builtin_fabsf(Q)));
+  }
+  if (j == 0u) {
+    if (tile_valid) saved[0] = count | (A << 10) | (sure_one ? 0x80000000u : 0u);
+    else if (slot_live) p.tile_lists[static_cast<size_t>(tslot) * (1u + p.bin_list)] = 0u;
+  }
 }
 
 // ------------------------------------------------------------------------------------

@@ -271,6 +271,7 @@ struct rt_tracer {
   // multi-device Resize: new frame size AND new band of it (scene, camera and options stay)
   void reshape(uint32_t w, uint32_t h, uint32_t r0, uint32_t n) {
     HIP_CHECK(hipStreamSynchronize(main_stream()));
+    sync_list_stream();
     release_buffers();
     W = w; H = h; row0 = r0; rows = n;
     list_key_valid = false;
@@ -420,20 +421,24 @@ struct rt_tracer {
     if (timed) { e = take_events(); e.launches = 1; e.split = r0 != 0u; }
     if (r0 == 0u) {
       (void)main_stream();                                               // a launch on one stream orders behind both
+      if (build_lists && !lists_inline) build_tile_lists_ahead(p);
       attach_tile_lists(p, have_lists);
       if (timed) HIP_CHECK(hipEventRecord(e.a, stream));
-      if (build_lists) HIP_CHECK(rtk::launch_tile_lists(p, fma, stream)); // part of the launch: timed with it
-      attach_macro_lists(p, 0, stream);                                  // (likewise)
+      if (build_lists && lists_inline) HIP_CHECK(rtk::launch_tile_lists(p, fma, stream));   // part of the launch: timed with it
+      if (have_lists) wait_for_lists(stream, list_waited_a);
+      attach_macro_lists(p, 0, stream);                                  // part of the launch: timed with it
       HIP_CHECK(rtk::launch_trace(p, fma, filter, bin, K, stream));
       if (timed) HIP_CHECK(hipEventRecord(e.b, stream));
     } else {
       fork_b();
+      if (build_lists && !lists_inline) build_tile_lists_ahead(p);
       rtk::TraceParams half[2] = {sub_band(p, 0u, r0), sub_band(p, r0, p.rows - r0)};
       hipStream_t st[2] = {stream, stream_b};
       if (timed) HIP_CHECK(hipEventRecord(e.a, stream));                 // the sampled duration is the upper half-frame kernel's
       for (int h = 0; h < 2; ++h) {
         attach_tile_lists(half[h], have_lists);
-        if (build_lists) HIP_CHECK(rtk::launch_tile_lists(half[h], fma, st[h]));   // each half builds the lists of its own rows
+        if (build_lists && lists_inline) HIP_CHECK(rtk::launch_tile_lists(half[h], fma, st[h]));   // each half builds the lists of its own rows
+        if (have_lists) wait_for_lists(st[h], h == 0 ? list_waited_a : list_waited_b);
         attach_macro_lists(half[h], h, st[h]);
         HIP_CHECK(rtk::launch_trace(half[h], fma, filter, bin, K, st[h]));
       }
@@ -542,8 +547,30 @@ struct rt_tracer {
     uint32_t W, H, row0, rows, bin_list, n_tris, scene_generation;
     bool fma;
   };
-  uint32_t* d_tile_lists = nullptr;
+  // The lists live in a small ring of buffers and are built on a stream of their own (stream_l, high priority): a build is
+  // enqueued when the launch that needs it is enqueued, so it runs UNDER the trace kernels of the previous launch instead of
+  // in front of its own (measured in-stream: each half-frame build took 35-45 us competing for wave slots with the other
+  // half's trace kernel and stalled its own stream meanwhile, profiles/r03_a_lists_inline_timeline.txt).  Ordering: the trace
+  // streams wait for list_ready[slot] (recorded on stream_l behind the build); a build into a slot waits for the events
+  // recorded on the trace streams when that slot was retired (its last readers), kListRing - 1 builds earlier.
+  // RT_MI355X_LISTS_INLINE=1: build on the trace streams, one slot (A/B).
+  static constexpr int kListRing = 3;
+  uint32_t* d_list_ring[kListRing] = {nullptr, nullptr, nullptr};
+  hipEvent_t list_ready[kListRing] = {nullptr, nullptr, nullptr};
+  hipEvent_t list_free_a[kListRing] = {nullptr, nullptr, nullptr}, list_free_b[kListRing] = {nullptr, nullptr, nullptr};
+  bool list_free_valid[kListRing] = {false, false, false};
+  int list_cur = 0;                   // slot of the current lists
+  uint64_t list_builds = 0;           // builds so far; the trace streams remember which one they have waited for
+  uint64_t list_waited_a = 0, list_waited_b = 0;
+  hipStream_t stream_l = nullptr;
+  bool lists_inline = false;
   size_t tile_lists_words = 0;
+  uint32_t* tile_lists_now() const { return d_list_ring[list_cur]; }
+  void release_tile_lists() {         // callers have synchronised every stream
+    for (int r = 0; r < kListRing; ++r) { if (d_list_ring[r]) (void)hipFree(d_list_ring[r]); d_list_ring[r] = nullptr; list_free_valid[r] = false; }
+    tile_lists_words = 0; list_key_valid = false; list_cur = 0;
+  }
+  void sync_list_stream() { if (stream_l) HIP_CHECK(hipStreamSynchronize(stream_l)); }
   ListKey list_key{};
   bool list_key_valid = false;
   uint32_t scene_generation = 0;
@@ -560,10 +587,15 @@ struct rt_tracer {
     const size_t tiles = static_cast<size_t>((W + 31u) / 32u) * ((rows + 7u) / 8u + 1u) * 4u;   // (+1: a split adds a partial block row)
     const size_t words = tiles * (1u + p.bin_list);
     if (words > tile_lists_words) {
-      if (d_tile_lists) (void)hipFree(d_tile_lists);
-      d_tile_lists = nullptr; tile_lists_words = 0; list_key_valid = false;
-      HIP_CHECK(hipMalloc(&d_tile_lists, words * sizeof(uint32_t)));
-      HIP_CHECK(hipMemsetAsync(d_tile_lists, 0, words * sizeof(uint32_t), main_stream()));   // count 0 everywhere until a launch builds
+      HIP_CHECK(hipStreamSynchronize(main_stream()));
+      sync_list_stream();
+      release_tile_lists();
+      for (int r = 0; r < (lists_inline ? 1 : kListRing); ++r) {
+        HIP_CHECK(hipMalloc(&d_list_ring[r], words * sizeof(uint32_t)));
+        // count 0 everywhere until a launch builds; on the stream the builds run on (a hipMemset on the null stream is not
+        // ordered with the non-blocking streams and may land AFTER the first build)
+        HIP_CHECK(hipMemsetAsync(d_list_ring[r], 0, words * sizeof(uint32_t), lists_inline ? stream : stream_l));
+      }
       tile_lists_words = words;
     }
     ListKey k;
@@ -587,7 +619,33 @@ struct rt_tracer {
     p.tile_lists = nullptr;
     if (!have) return;
     const size_t slot_base = static_cast<size_t>((W + 31u) / 32u) * ((p.row0 - row0) / 8u) * 4u;
-    p.tile_lists = d_tile_lists + slot_base * (1u + p.bin_list);
+    p.tile_lists = tile_lists_now() + slot_base * (1u + p.bin_list);
+  }
+
+  // The lists of the whole band, built on stream_l into the next slot of the ring (see the fields' comment).
+  void build_tile_lists_ahead(const rtk::TraceParams& p_band) {
+    if (list_builds > 0) {                                             // retire the current slot: its last readers are what the trace streams hold now
+      HIP_CHECK(hipEventRecord(list_free_a[list_cur], stream));
+      HIP_CHECK(hipEventRecord(list_free_b[list_cur], stream_b));
+      list_free_valid[list_cur] = true;
+    }
+    const int r = static_cast<int>(list_builds % kListRing);
+    if (list_free_valid[r]) {
+      HIP_CHECK(hipStreamWaitEvent(stream_l, list_free_a[r], 0));
+      HIP_CHECK(hipStreamWaitEvent(stream_l, list_free_b[r], 0));
+    }
+    list_cur = r;
+    rtk::TraceParams q = p_band;
+    attach_tile_lists(q, true);
+    HIP_CHECK(rtk::launch_tile_lists(q, fma, stream_l));
+    HIP_CHECK(hipEventRecord(list_ready[r], stream_l));
+    ++list_builds;
+  }
+  // stream `st` (the primary stream or stream_b) is about to run a trace kernel that reads the current lists
+  void wait_for_lists(hipStream_t st, uint64_t& waited) {
+    if (lists_inline || waited == list_builds) return;
+    HIP_CHECK(hipStreamWaitEvent(st, list_ready[list_cur], 0));
+    waited = list_builds;
   }
 
   // Macro level of the classification (scenes that do not fit the per-wave list): sizes the
@@ -919,6 +977,22 @@ int rt_tracer_create_ex(const uint32_t imageSize[2], const float cameraPosition[
       else
         HIP_CHECK(hipStreamCreateWithFlags(&t->stream_b, hipStreamNonBlocking));
     }
+    {
+      const char* li = getenv("RT_MI355X_LISTS_INLINE");
+      t->lists_inline = li && li[0] == '1';
+      int lo = 0, hi = 0;                                                // (numerically lower = higher priority)
+      if (!t->lists_inline) {
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo && !getenv("RT_MI355X_LISTS_NO_PRIO"))
+          HIP_CHECK(hipStreamCreateWithPriority(&t->stream_l, hipStreamNonBlocking, hi));
+        else
+          HIP_CHECK(hipStreamCreateWithFlags(&t->stream_l, hipStreamNonBlocking));
+      }
+      for (int r = 0; r < rt_tracer::kListRing; ++r) {
+        HIP_CHECK(hipEventCreateWithFlags(&t->list_ready[r], hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&t->list_free_a[r], hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&t->list_free_b[r], hipEventDisableTiming));
+      }
+    }
     HIP_CHECK(hipEventCreateWithFlags(&t->handoff_event, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&t->join_event, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&t->fork_event, hipEventDisableTiming));
@@ -964,7 +1038,14 @@ void rt_tracer_destroy(rt_tracer* t) {                                   // RayT
   if (t->stream) (void)hipStreamSynchronize(t->stream);
   t->drain_events();
   for (EventPair& e : t->free_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); (void)hipEventDestroy(e.c); }
-  if (t->d_tile_lists) (void)hipFree(t->d_tile_lists);
+  if (t->stream_l) (void)hipStreamSynchronize(t->stream_l);
+  t->release_tile_lists();
+  for (int r = 0; r < rt_tracer::kListRing; ++r) {
+    if (t->list_ready[r]) (void)hipEventDestroy(t->list_ready[r]);
+    if (t->list_free_a[r]) (void)hipEventDestroy(t->list_free_a[r]);
+    if (t->list_free_b[r]) (void)hipEventDestroy(t->list_free_b[r]);
+  }
+  if (t->stream_l) (void)hipStreamDestroy(t->stream_l);
   for (int h = 0; h < 2; ++h) if (t->d_macro_lists[h]) (void)hipFree(t->d_macro_lists[h]);
   if (t->d_tri_n) (void)hipFree(t->d_tri_n);
   if (t->d_tri) (void)hipFree(t->d_tri);
@@ -1063,6 +1144,7 @@ static int upload_scene_impl(rt_tracer* t, const rt_float4* hostData, size_t cou
     t->cancel_and_join();
     t->use_device();
     HIP_CHECK(hipStreamSynchronize(t->main_stream()));
+    t->sync_list_stream();                                               // (a list build may still be reading the old records)
     if (t->d_tri) { (void)hipFree(t->d_tri); t->d_tri = nullptr; }       // :128-137
     if (t->d_tri_b) { (void)hipFree(t->d_tri_b); t->d_tri_b = nullptr; }
     if (t->d_tri_color) { (void)hipFree(t->d_tri_color); t->d_tri_color = nullptr; }
@@ -1265,8 +1347,10 @@ int rt_tracer_trace_stats(rt_tracer* t, uint32_t samples, uint64_t out[16]) {
     p.flags = t->mode_flags(p);
     bool have_lists = false;
     const bool build_lists = t->prepare_tile_lists(p, true, have_lists);
+    t->sync_list_stream();                                               // (a synchronous path: build in-stream into the current slot)
     t->attach_tile_lists(p, have_lists);
-    if (build_lists) HIP_CHECK(rtk::launch_tile_lists(p, t->fma, t->main_stream()));
+    if (have_lists) HIP_CHECK(rtk::launch_tile_lists(p, t->fma, t->main_stream()));
+    (void)build_lists;
     t->attach_macro_lists(p, 0, t->main_stream());
     HIP_CHECK(rtk::launch_trace(p, t->fma, t->filter, t->bin, t->pick_k(samples), t->main_stream()));
     HIP_CHECK(hipStreamSynchronize(t->main_stream()));
@@ -1281,6 +1365,7 @@ int rt_tracer_sync(rt_tracer* t) {
     t->use_device();
     const uint64_t seen = t->event_seq_now();        // launches enqueued so far; a running render thread may add more
     HIP_CHECK(hipStreamSynchronize(t->main_stream()));
+    t->sync_list_stream();                           // (nothing the caller could read depends on it; a Sync leaves the device idle)
     t->drain_events_before(seen);
     if (t->grp) t->grp->sync();
   });
@@ -1574,8 +1659,10 @@ extern "C" int rt_dbg_trace_timeline(rt_tracer* t, uint32_t samples, unsigned lo
     p.timeline = buf.as<unsigned long long>();
     bool have_lists = false;
     const bool build_lists = t->prepare_tile_lists(p, true, have_lists);
+    t->sync_list_stream();
     t->attach_tile_lists(p, have_lists);
-    if (build_lists) HIP_CHECK(rtk::launch_tile_lists(p, t->fma, t->main_stream()));
+    if (have_lists) HIP_CHECK(rtk::launch_tile_lists(p, t->fma, t->main_stream()));
+    (void)build_lists;
     t->attach_macro_lists(p, 0, t->main_stream());
     HIP_CHECK(rtk::launch_trace(p, t->fma, t->filter, t->bin, t->pick_k(samples), t->main_stream()));
     HIP_CHECK(hipStreamSynchronize(t->main_stream()));
@@ -1593,9 +1680,10 @@ int rt_dbg_read_tile_lists(rt_tracer* t, uint32_t* dst, size_t capacity_words, u
     t->cancel_and_join();
     t->use_device();
     HIP_CHECK(hipStreamSynchronize(t->main_stream()));
-    if (!t->d_tile_lists || !t->list_key_valid) throw HipFail{"no tile lists (small scenes build them ahead of their first trace launch)"};
+    t->sync_list_stream();
+    if (!t->tile_lists_now() || !t->list_key_valid) throw HipFail{"no tile lists (small scenes build them ahead of their first trace launch)"};
     const size_t n = t->tile_lists_words < capacity_words ? t->tile_lists_words : capacity_words;
-    HIP_CHECK(hipMemcpy(dst, t->d_tile_lists, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(dst, t->tile_lists_now(), n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (words_per_tile) *words_per_tile = 1u + t->list_key.bin_list;
   });
 }
@@ -1673,14 +1761,14 @@ int rt_dbg_focal_boxes(rt_tracer* t, float curv_scale, float* boxes, size_t boxe
 
 int rt_dbg_classify(rt_tracer* t, uint32_t level, uint32_t forms, uint32_t slack_milli, const uint32_t* regions, uint32_t n_regions,
                     float* out, size_t capacity_floats) {
-  if (!t || t->mg || !regions || !out || level > 2u) return RT_ERR_INVALID;
+  if (!t || t->mg || !regions || !out || level > 3u) return RT_ERR_INVALID;
   std::lock_guard<std::mutex> lk(t->api_mu);
   return guarded(t, [&] {
     t->cancel_and_join();
     t->use_device();
     rtk::TraceParams p = t->params(1);
     p.macro_w = rt_tracer::kMacroW; p.macro_h = rt_tracer::kMacroH;      // level 2: the macro tile of attach_macro_lists
-    const uint32_t rw = level == 0u ? 8u : level == 1u ? 32u : p.macro_w, rh = level == 2u ? p.macro_h : 8u;
+    const uint32_t rw = level == 0u ? 8u : level == 2u ? p.macro_w : 32u, rh = level == 2u ? p.macro_h : level == 3u ? 16u : 8u;
     for (uint32_t i = 0; i < n_regions; ++i)                             // the kernel's pixel <-> lane mapping assumes the trace grid
       if (regions[2u * i] % rw != 0u || regions[2u * i + 1u] % rh != 0u || regions[2u * i] >= t->W || regions[2u * i + 1u] >= t->rows)
         throw HipFail{fmt("region %u (%u, %u) is not a level-%u region of the %ux%u band", i, regions[2u * i], regions[2u * i + 1u], level, t->W, t->rows)};

@@ -8,7 +8,8 @@ wrongly dropped triangle that is not the farthest hit (Kernels.cuh:73,84), so th
   device side   rt_dbg_classify (include/rt_mi355x.h): for a region of the frame -- an 8x8 wave tile, a 32x8 block, a
                 128x64 macro tile, bounded exactly as the trace path bounds them -- and EVERY triangle: kept / certainly
                 hit, and the interval ends det', U', V', q the verdict was taken from, at the product's rounding allowances
-                (scale 1) and with every allowance scaled to 0.3 ... 0;
+                (scale 1) and with every allowance scaled to 0.3 ... 0 (level 3: the 32x16 region of the small scenes'
+                two-level list builder); rt_dbg_read_tile_lists: the lists and certain-winner verdicts the product stored;
   oracle side   orc_tile_probe (oracle/oracle.h): the reference's HitTriangle arithmetic and farthest-hit scan for the rays
                 of every pixel of the region x a set of lens samples (rim of the lens, centre, the pixels' own RNG stream)
                 against every triangle.
@@ -188,12 +189,29 @@ def check_region(tag, probe, nohit, rays, recs, hdrs, forms=False, tile_word=Non
         win = certain_winner(recs[1000], usable)
         if win is not None:
             t.sure_tiles = 1
-        if tile_word is not None:                             # the product's own stored verdict for this tile
+        if tile_word is not None:
+            # The PRODUCT's own list and verdict for this tile (rt_dbg_read_tile_lists).  The two-level builder keeps what
+            # survives the region's family AND the tile's: a subset of the tile-level verdicts exported here, ascending.  The
+            # checks that matter run on the product's list itself: nothing it dropped is hit, its winner wins every ray.
             cnt, pw, pflag = int(tile_word & 0x3FF), int((tile_word >> 10) & 0x3FF), bool(tile_word >> 31)
-            exp = np.flatnonzero(keep1)
-            assert cnt == exp.size and np.array_equal(stored_list[:cnt], exp), "%s: the stored list differs from rt_dbg_classify: %s vs %s" % (tag, stored_list[:cnt], exp)
-            hw = win if n <= SURE_MAX_TRIS else None
+            lst = stored_list[:cnt].astype(np.int64)
+            assert cnt <= n and (np.diff(lst) > 0).all() and (lst < n).all(), "%s: stored list not ascending / out of range: %s" % (tag, lst)
+            pk = np.zeros(n, bool)
+            pk[lst] = True
+            assert not (pk & ~keep1).any(), "%s: the product keeps triangles the tile-level classification drops: %s vs %s" % (tag, lst, np.flatnonzero(keep1))
+            b = t.bad[1000]
+            b["drop_hit"] = int(((~pk) & (real_hits > 0)).sum())
+            b["drop_win"] = int(((~pk) & (wins > 0)).sum())
+            t.kept, t.dropped = int(pk.sum()), int((~pk).sum())
+            rec_p = recs[1000].copy()
+            rec_p[~pk, 0] = 0.0                                # the winner rule over the product's candidates
+            hw = certain_winner(rec_p, usable) if n <= SURE_MAX_TRIS else None
             assert pflag == (hw is not None) and (not pflag or pw == hw), "%s: stored certain-winner verdict (%s, %d) vs harness %s" % (tag, pflag, pw, hw)
+            b["tile_winner"] = int(pflag and wins[pw] != rays)
+            t.sure_tiles = int(pflag)
+            if (b["drop_hit"] or b["tile_winner"]) and len(t.examples) < 12:
+                t.examples.append("%s: product list %s flag %s winner %d: hits on dropped %s, winner wins %d of %d rays" % (
+                    tag, lst.tolist(), pflag, pw, np.flatnonzero((~pk) & (real_hits > 0)).tolist(), wins[pw] if pflag else -1, rays))
     if usable:
         r0 = recs[0].astype(np.float64) if 0 in recs else None
         fin = np.isfinite(r1[:, 1:7]).all(axis=1) & (probe["nan_rays"] == 0)
@@ -264,8 +282,10 @@ def run(g, o, regions, level, lens, *, forms=False, ladder=LADDER, max_pixels=No
     """Check `regions` [(x0, y0) band-local] of tracer `g` (api.RayTracer) against oracle tracer `o` (same scene, camera,
     frame).  stored: g.DebugTileListWords() to cross-check the product's own lists (level 0, small scenes).  -> Tally"""
     regions = np.ascontiguousarray(regions, np.uint32).reshape(-1, 2)
-    rw, rh = {0: (8, 8), 1: (32, 8), 2: (128, 64)}[level]
+    rw, rh = {0: (8, 8), 1: (32, 8), 2: (128, 64), 3: (32, 16)}[level]
     out = {s: g.DebugClassify(regions, level, forms, s) for s in ladder}
+    if level == 3 and not (int(out[ladder[0]][0][0][8]) & 4):
+        return Tally()                                      # the two-level list builder is not in use for this camera / frame
     rng = np.random.default_rng(7)
     pixsets = [region_pixels(int(x0), int(y0), rw, rh, g.width, g.rows, row0, max_pixels, rng) for x0, y0 in regions]
 

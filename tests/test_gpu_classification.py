@@ -67,7 +67,7 @@ def test_adversarial_scenes_per_tile_and_triangle(rt, orc):
     from raytracertest_amd import scenes
     rng = np.random.default_rng(20261)
     lens = cc.lens_samples(orc, seed=5, pixel_index=11)
-    total, onepass = cc.Tally(), 0
+    total, regions, onepass = cc.Tally(), cc.Tally(), 0
     for it in range(N_ADV + N_COVER):
         c = adversarial_config(rng) if it < N_ADV else cover_config(rng)
         n = c["tris"].shape[0]
@@ -79,12 +79,16 @@ def test_adversarial_scenes_per_tile_and_triangle(rt, orc):
             onepass += 1
         t = cc.run(g, o, all_tiles(c["W"], c["H"]), 0, lens, stored=stored, tag="adv%d(n=%d, scale=%.3g)" % (it, n, c["scale"]))
         total.merge(t)
+        if n <= 256:                                        # the region level of the two-level list builder
+            regions.merge(cc.run(g, o, [(x, y) for y in range(0, c["H"], 16) for x in range(0, c["W"], 32)], 3, lens, ladder=(1000, 0),
+                                 tag="adv%d region" % it))
         if n > 256:                                         # block level of the larger scenes
             total.merge(cc.run(g, o, [(x, y) for y in range(0, c["H"], 8) for x in range(0, c["W"], 32)], 1, lens, tag="adv%d" % it))
         g.close()
     s = clean(total, "adversarial scenes")
     s["configurations"], s["with_product_lists_cross_checked"] = N_ADV + N_COVER, onepass
     REPORT["adversarial"] = s
+    REPORT["adversarial_regions"] = clean(regions, "adversarial scenes, region level")
     assert total.dropped > 0 and total.sure > 100 and total.sure_tiles > 50
     # teeth: with no rounding allowance at all the reference's values DO leave the intervals (the test can see rounding),
     # and the product charges a multiple of what they need
@@ -107,6 +111,9 @@ def test_c3_every_tile_of_the_benchmarked_frame(rt, orc):
     tiles = all_tiles(cfg["width"], cfg["height"])
     t = cc.run(g, o, tiles, 0, small, stored=stored, ladder=(1000, 0), tag="C3")
     t2 = cc.run(g, o, tiles[::8], 0, lens, stored=stored, tag="C3")
+    t3 = cc.run(g, o, [(x, y) for y in range(0, cfg["height"], 16) for x in range(0, cfg["width"], 32)], 3, small, ladder=(1000, 0),
+                max_pixels=128, tag="C3 region")
+    REPORT["C3_regions"] = clean(t3, "C3 regions")
     g.close()
     s = clean(t, "C3 all tiles")
     s2 = clean(t2, "C3 every 8th tile, full lens set")

@@ -21,6 +21,10 @@ g = R.RayTracer((cfg["width"], cfg["height"]), (0, 0, 0), cfg["angles"], cfg["fo
 if tris.shape[0]: g.UploadScene(tris)
 if sph.shape[0]: g.UploadSpheres(sph)
 import time
+from raytracertest_amd import api
+if %(preheat)r:
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.15: api.dbg_valu_peak(0)      # steady clocks, as bench.py does
 if %(cold)r: g.SetListReuse(False)             # bench.py's headline mode: every step classifies afresh
 for _ in range(%(warmup)d): g.TraceEnqueue(1, cfg["samples"])
 g.Sync(); g.KernelTime()
@@ -38,15 +42,20 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--preheat", action="store_true", help="150 ms of the VALU calibration loop before the warmup steps (steady clocks)")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     variants = []
     for v in a.variants:
         name, rest = v.split("=", 1)
         parts = rest.split(",")
-        opts = {"lib": parts[0], "k": 0, "chunk": 0, "nofilter": False, "nobin": False, "binlist": 0, "cold": False}
+        opts = {"lib": parts[0], "k": 0, "chunk": 0, "nofilter": False, "nobin": False, "binlist": 0, "cold": False, "env": {}}
         for p in parts[1:]:
             key, val = p.split("=")
+            if key == "env":                              # env=NAME:VALUE for this variant's subprocess
+                k2, v2 = val.split(":", 1)
+                opts["env"][k2] = v2
+                continue
             opts[key] = (val == "1") if key in ("nofilter", "nobin", "cold") else int(val)
         variants.append((name, opts))
     res = {n: [] for n, _ in variants}
@@ -54,10 +63,11 @@ def main():
     for _ in range(a.rounds):
         for name, o in variants:
             env = dict(os.environ)
+            env.update(o["env"])
             lib = o["lib"]
             env["RT_MI355X_LIB"] = lib if os.path.isabs(lib) else os.path.join(ROOT, "raytracertest_amd", "lib", lib)
             code = CHILD % dict(root=ROOT, config=a.config, k=o["k"], chunk=o["chunk"], nofilter=o["nofilter"], nobin=o["nobin"], binlist=o["binlist"],
-                                cold=o["cold"], warmup=a.warmup, steps=a.steps)
+                                cold=o["cold"], warmup=a.warmup, steps=a.steps, preheat=a.preheat)
             out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
             if out.returncode != 0:
                 print(name, "FAILED", out.stderr[-400:])

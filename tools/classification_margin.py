@@ -21,7 +21,7 @@ out_path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "gpurun_out"
 rng = np.random.default_rng(seed)
 lens = cc.lens_samples(orc, seed=seed, pixel_index=3)
 small = np.concatenate([lens[:1], lens[1:113:2], lens[-8:]])
-tallies = {"small_scenes": cc.Tally(), "cover_scenes": cc.Tally(), "large_scenes_wave_forms": cc.Tally(),
+tallies = {"small_scenes": cc.Tally(), "cover_scenes": cc.Tally(), "small_scenes_region_level": cc.Tally(), "large_scenes_wave_forms": cc.Tally(),
            "large_scenes_block": cc.Tally(), "large_scenes_macro": cc.Tally()}
 t0 = time.time()
 for it in range(N + N // 2):
@@ -50,6 +50,9 @@ for it in range(N + N // 2):
             g.Trace(1, 1, 0); assert g.Wait()
             stored = g.DebugTileListWords()
         tallies["cover_scenes" if kind == "cover" else "small_scenes"].merge(cc.run(g, o, tiles, 0, lens, stored=stored, tag=tag))
+        if n <= 256:
+            regs = [(x, y) for y in range(0, c["H"], 16) for x in range(0, c["W"], 32)]
+            tallies["small_scenes_region_level"].merge(cc.run(g, o, regs, 3, lens, ladder=(1000, 100, 0), tag=tag))
     g.close()
     if it % 50 == 49:
         print("... %d/%d configurations, %.0f s; needed scale so far %.4f" % (it + 1, N + N // 2, time.time() - t0,
