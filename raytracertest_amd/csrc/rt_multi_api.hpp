@@ -20,6 +20,8 @@ void multi_sync_all(rt_tracer* t) {
     b->use_device();
     const uint64_t seen = b->event_seq_now();        // a running render thread may enqueue more meanwhile
     HIP_CHECK(hipStreamSynchronize(b->main_stream()));
+    b->sync_list_stream();
+    b->stagger_next = true;
     b->drain_events_before(seen);
   }
   m.group.sync();

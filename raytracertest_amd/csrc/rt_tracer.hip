@@ -432,6 +432,12 @@ struct rt_tracer {
     } else {
       fork_b();
       if (build_lists && !lists_inline) build_tile_lists_ahead(p);
+      // The two halves overlap best in ANTI-phase (one half's drain under the other's bulk); started together -- both
+      // released by the same event, or from an idle device -- they can lock IN phase and stay there for a whole run
+      // (measured at C3: 93 instead of 80 us per step, profiles/r03_b_phase_regimes.txt).  The first split launch after
+      // the tracer was idle therefore lets its lower half start behind its upper half: a stagger of one half-frame kernel
+      // that has the device to itself, i.e. about half a step, whatever the workload.  Later launches free-run.
+      const bool stagger = stagger_next.exchange(false) && !no_stagger;
       rtk::TraceParams half[2] = {sub_band(p, 0u, r0), sub_band(p, r0, p.rows - r0)};
       hipStream_t st[2] = {stream, stream_b};
       if (timed) HIP_CHECK(hipEventRecord(e.a, stream));                 // the sampled duration is the upper half-frame kernel's
@@ -439,8 +445,10 @@ struct rt_tracer {
         attach_tile_lists(half[h], have_lists);
         if (build_lists && lists_inline) HIP_CHECK(rtk::launch_tile_lists(half[h], fma, st[h]));   // each half builds the lists of its own rows
         if (have_lists) wait_for_lists(st[h], h == 0 ? list_waited_a : list_waited_b);
+        if (h == 1 && stagger) HIP_CHECK(hipStreamWaitEvent(stream_b, stagger_event, 0));
         attach_macro_lists(half[h], h, st[h]);
         HIP_CHECK(rtk::launch_trace(half[h], fma, filter, bin, K, st[h]));
+        if (h == 0 && stagger) HIP_CHECK(hipEventRecord(stagger_event, stream));
       }
       if (timed) { HIP_CHECK(hipEventRecord(e.b, stream)); HIP_CHECK(hipEventRecord(e.c, stream_b)); }
       mark_b_dirty();
@@ -564,6 +572,9 @@ struct rt_tracer {
   uint64_t list_waited_a = 0, list_waited_b = 0;
   hipStream_t stream_l = nullptr;
   bool lists_inline = false;
+  std::atomic<bool> stagger_next{true};   // the next split launch starts from an idle tracer: stagger its halves (enqueue_trace_launch)
+  hipEvent_t stagger_event = nullptr;
+  bool no_stagger = false;                // RT_MI355X_NO_STAGGER=1 (A/B)
   size_t tile_lists_words = 0;
   uint32_t* tile_lists_now() const { return d_list_ring[list_cur]; }
   void release_tile_lists() {         // callers have synchronised every stream
@@ -987,6 +998,8 @@ int rt_tracer_create_ex(const uint32_t imageSize[2], const float cameraPosition[
         else
           HIP_CHECK(hipStreamCreateWithFlags(&t->stream_l, hipStreamNonBlocking));
       }
+      HIP_CHECK(hipEventCreateWithFlags(&t->stagger_event, hipEventDisableTiming));
+      { const char* ns2 = getenv("RT_MI355X_NO_STAGGER"); t->no_stagger = ns2 && ns2[0] == '1'; }
       for (int r = 0; r < rt_tracer::kListRing; ++r) {
         HIP_CHECK(hipEventCreateWithFlags(&t->list_ready[r], hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&t->list_free_a[r], hipEventDisableTiming));
@@ -1046,6 +1059,7 @@ void rt_tracer_destroy(rt_tracer* t) {                                   // RayT
     if (t->list_free_b[r]) (void)hipEventDestroy(t->list_free_b[r]);
   }
   if (t->stream_l) (void)hipStreamDestroy(t->stream_l);
+  if (t->stagger_event) (void)hipEventDestroy(t->stagger_event);
   for (int h = 0; h < 2; ++h) if (t->d_macro_lists[h]) (void)hipFree(t->d_macro_lists[h]);
   if (t->d_tri_n) (void)hipFree(t->d_tri_n);
   if (t->d_tri) (void)hipFree(t->d_tri);
@@ -1366,6 +1380,7 @@ int rt_tracer_sync(rt_tracer* t) {
     const uint64_t seen = t->event_seq_now();        // launches enqueued so far; a running render thread may add more
     HIP_CHECK(hipStreamSynchronize(t->main_stream()));
     t->sync_list_stream();                           // (nothing the caller could read depends on it; a Sync leaves the device idle)
+    t->stagger_next = true;
     t->drain_events_before(seen);
     if (t->grp) t->grp->sync();
   });
