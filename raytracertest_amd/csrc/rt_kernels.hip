@@ -165,8 +165,9 @@ __global__ __launch_bounds__(256) void dbg_focal_boxes_kernel(const TraceParams 
 //   out[region] = 16 header floats: focal lo[3], hi[3], lmin, lmax, usable (+ 2: the focal-bound paths agree, + 4: p.tile_curv > 0, the two-level list builder is in use), A, orad[3], fc[3]
 //               + n_tris x stride floats: flags (1 keep | 2 certainly hit), det_lo, det_hi, U_lo, U_hi, V_lo, V_hi,
 //                 q_lo, q_hi, Nt_lo, Nt_hi, 0 (stride 12; the small-scene instantiation <false, SURE>), or, FORMS:
-//                 flags (1 keep), the same six ends, 5 x 0, then the 18 numbers of the per-sample forms with the gradients
-//                 [9..17] rounded to bf16 as the trace kernel stores them (stride 32; the large-scene instantiation).
+//                 flags (1 keep), the same six ends, 5 x 0, then the 18 numbers of the per-sample forms -- each form scaled by
+//                 its power of two, the gradients [9..17] the fp16 values the trace kernel stores (stride 32; the large-scene
+//                 instantiation).
 // ------------------------------------------------------------------------------------
 template <bool FMA, bool FORMS, class SL>
 __global__ __launch_bounds__(256) void dbg_classify_kernel(const TraceParams p, uint32_t level, const uint32_t* __restrict__ regions,
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(256) void dbg_classify_kernel(const TraceParams p, 
 #pragma unroll
       for (int i = 0; i < 9; ++i) r[12 + i] = forms[i];
 #pragma unroll
-      for (int i = 9; i < 18; ++i) r[12 + i] = __builtin_bit_cast(float, bf16_bits(forms[i]) << 16);
+      for (int i = 9; i < 18; ++i) r[12 + i] = forms[i];           // fp16-exact values, as the trace kernel stores them
       r[30] = 0.0f; r[31] = 0.0f;
     } else {
       bool keep = true, sure = false;

@@ -35,7 +35,7 @@ using rtd::V3;
 // relative to a magnitude, and factors 1 + x).  RT_BIN_SLACK_SCALE = 1 in the product; the teeth test of the
 // adversarial campaign builds the library with the allowances scaled down (tools/stress_boundaries.py must then
 // FIND mismatches: profiles/r02_boundary_campaign.txt) -- the thresholds that come from proofs about the
-// reference's own tests (-1e-6 det, 1.0002 det) and the bf16 quantisation bound are not scaled.
+// reference's own tests (-1e-6 det, 1.0002 det) and the fp16 quantisation bound of the forms are not scaled.
 #ifndef RT_BIN_SLACK_SCALE
 #define RT_BIN_SLACK_SCALE 1.0f
 #endif
@@ -400,9 +400,6 @@ __device__ __forceinline__ TileFamily make_family(const TraceParams& p, const Fo
   return f;
 }
 
-// fp32 -> bf16 bits, round to nearest (ties up): how the per-sample forms' gradients are stored in LDS
-__device__ __forceinline__ uint32_t bf16_bits(float x) { return (__builtin_bit_cast(uint32_t, x) + 0x8000u) >> 16; }
-
 // Per-sample forms (FORMS = true, large-scene kernels).  For ONE ray the lens origin is known: do =
 // o - oc exactly (up to the rounding already inside a_r below), only the focal point keeps its box.
 // The same expansion then bounds the ray's own det', U', V' by AFFINE functions of (do.x, do.y),
@@ -413,8 +410,8 @@ __device__ __forceinline__ uint32_t bf16_bits(float x) { return (__builtin_bit_c
 // (if det_hi <= 0 the ray is culled and any verdict is right): F_i(do) < 0 for some i  =>  the
 // reference's test misses for this ray.  The focal point enters U', V', det' linearly (dF.(e2 x tvc),
 // dF.(tvc x e1), dF.N) apart from the small bilinear do x dF terms, and each lane knows its own
-// dF = F - fc: the linear parts are evaluated per lane from the forms' gradients g_i (kept as bf16,
-// their quantisation and the rounding of dF charged to the constant terms), so that the focal BOX only
+// dF = F - fc: the linear parts are evaluated per lane from the forms' gradients g_i (kept as fp16 after a
+// per-form power-of-two scaling, their quantisation and the rounding of dF charged to the constant terms), so that the focal BOX only
 // bounds the bilinear terms -- which is what lifts the rejection from 61 % to ~88 % of C4's tests.
 // forms[] = {F1.c0, F1.cx, F1.cy, F2.c0, F2.cx, F2.cy, F3.c0, F3.cx, F3.cy, g1.xyz, g2.xyz, g3.xyz};
 // the trace loop evaluates F_i = c0 + g.dF (per lane and candidate) + cx do.x + cy do.y (per sample) and only enters the
@@ -512,9 +509,8 @@ __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0,
       UR += a_r * __builtin_fabsf(Gxe2) + a[i] * rxe2 + c * (T[i] * Wxe2 + a[i] * Gabs);
       VR += a_r * __builtin_fabsf(e1xG) + r[i] * axe1 + c * (W[i] * Txe1 + a[i] * Gabs);
       Nv[i] = N_i; Gu[i] = Gxe2; Gv[i] = e1xG; Eu[i] = e2xt; Ev[i] = txe1;
-      // what a lane's dF can be off by: bf16 storage of the gradients (2^-8 relative, on |dF_i| <= r_i) and
-      // the rounding of F - fc itself
-      qd[i] = 0.00390625f * r[i] + RT_SLK(2e-7f) * (__builtin_fabsf(f.fc[i]) + r[i]);
+      // what a lane's dF can be off by: the rounding of F - fc itself (the storage of the gradients is charged below)
+      qd[i] = RT_SLK(2e-7f) * (__builtin_fabsf(f.fc[i]) + r[i]);
     }
   }
   if constexpr (FORMS) {
@@ -536,6 +532,28 @@ __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0,
       forms[0] += qd[i] * __builtin_fabsf(g1) * RT_SLKM(1e-5f);
       forms[3] += qd[i] * __builtin_fabsf(g2) * RT_SLKM(1e-5f);
       forms[6] += qd[i] * __builtin_fabsf(g3) * RT_SLKM(1e-5f);
+    }
+    // The gradients are kept as fp16 (v_fma_mix_f32 reads the halves in place: no unpacking in the per-sample loop).  Only
+    // the SIGN of a form matters, so each form is first scaled by the power of two that brings its largest gradient
+    // component into [2^13, 2^14) -- exact, and far from fp16's overflow -- and then rounded to nearest: a component is
+    // off by at most 2^-11 of itself (normal range) or 2^-25 (below 2^-14), times |dF_i| <= r_i; charged to the constant
+    // term, not scaled with the rounding allowances (it is a bound on a known quantisation).
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float m = fmaxf(fmaxf(__builtin_fabsf(forms[9 + 3 * k]), __builtin_fabsf(forms[10 + 3 * k])), __builtin_fabsf(forms[11 + 3 * k]));
+      int n = 14 - __builtin_amdgcn_frexp_expf(m);
+      n = (m > 0.0f && m <= FLT_MAX) ? (n < -100 ? -100 : n > 100 ? 100 : n) : 0;
+      float quant = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float gs = __builtin_ldexpf(forms[9 + 3 * k + j], n);
+        const float gq = static_cast<float>(static_cast<_Float16>(gs));
+        quant += (0.00048828125f * __builtin_fabsf(gs) + 2.98023224e-8f) * r[j];
+        forms[9 + 3 * k + j] = gq;
+      }
+      forms[3 * k] = __builtin_ldexpf(forms[3 * k], n) + quant * 1.001f;
+      forms[3 * k + 1] = __builtin_ldexpf(forms[3 * k + 1], n);
+      forms[3 * k + 2] = __builtin_ldexpf(forms[3 * k + 2], n);
     }
   }
   // The lens is a DISK of radius A, the sums above took it as the box [-A, A]^2: a term do.g (do_z = 0) was charged
@@ -1086,12 +1104,19 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   auto tl_mark = [](uint32_t) {};
 #endif
   Rng rng;                                                         // :131
-  rng.d = p.rng[0 * static_cast<size_t>(p.npix) + pix];
-  rng.v0 = p.rng[1 * static_cast<size_t>(p.npix) + pix];
-  rng.v1 = p.rng[2 * static_cast<size_t>(p.npix) + pix];
-  rng.v2 = p.rng[3 * static_cast<size_t>(p.npix) + pix];
-  rng.v3 = p.rng[4 * static_cast<size_t>(p.npix) + pix];
-  rng.v4 = p.rng[5 * static_cast<size_t>(p.npix) + pix];
+  auto load_rng = [&] {
+    rng.d = p.rng[0 * static_cast<size_t>(p.npix) + pix];
+    rng.v0 = p.rng[1 * static_cast<size_t>(p.npix) + pix];
+    rng.v1 = p.rng[2 * static_cast<size_t>(p.npix) + pix];
+    rng.v2 = p.rng[3 * static_cast<size_t>(p.npix) + pix];
+    rng.v3 = p.rng[4 * static_cast<size_t>(p.npix) + pix];
+    rng.v4 = p.rng[5 * static_cast<size_t>(p.npix) + pix];
+  };
+  // Dense-scene kernels with the per-sample forms (PRE) classify BEFORE any ray exists; six state registers held across the
+  // block- and wave-level classification are what made the 128-VGPR kernel spill (32 bytes of scratch per lane): their state
+  // is requested behind the classification instead (one exposed load latency per wave, hidden by the other three waves).
+  constexpr bool RNG_LATE = PRE && BIN && !ONEPASS;
+  if constexpr (!RNG_LATE) load_rng();
 
 
   // Small scenes (ONEPASS): the tile's candidate list and its certain-winner verdict were built ahead of this launch by
@@ -1145,7 +1170,7 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   int* const cI = reinterpret_cast<int*>(s_mem + 4u * 2u * L) + 4u * L + wave * L;
   // PRETEST (large-scene kernels, TRACE_PRETEST): one 64-byte block more per candidate behind the index
   // array -- the three per-sample forms of tile_misses_triangle<true> (9 floats) and their focal-point
-  // gradients (9 bf16 in 5 dwords), contiguous so that one address register and four ds_read_b128
+  // gradients (9 fp16 in 5 dwords), contiguous so that one address register and four ds_read_b128
   // with immediate offsets fetch them.  L is a multiple of 2 here.
   constexpr bool PRETEST = PRE && BIN && !ONEPASS;
   const bool pretest = PRETEST && (p.flags & TRACE_PRETEST) != 0u;   // wave-uniform
@@ -1261,7 +1286,10 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
         cI[pos] = static_cast<int>(tri);
         if constexpr (PRETEST && WF) {
           if (pretest) {
-            auto pk = [&](float hi, float lo) { return __builtin_bit_cast(float, (bf16_bits(hi) << 16) | bf16_bits(lo)); };
+            auto pk = [&](float hi, float lo) {                        // two fp16 (the values are fp16-exact already) in one word
+              const uint32_t h = __builtin_bit_cast(uint16_t, static_cast<_Float16>(hi)), l = __builtin_bit_cast(uint16_t, static_cast<_Float16>(lo));
+              return __builtin_bit_cast(float, (h << 16) | l);
+            };
             cP[4u * pos] = make_float4(forms[0], forms[1], forms[2], forms[3]);
             cP[4u * pos + 1u] = make_float4(forms[4], forms[5], forms[6], forms[7]);
             cP[4u * pos + 2u] = make_float4(forms[8], pk(forms[9], forms[10]), pk(forms[11], forms[12]), pk(forms[13], forms[14]));
@@ -1316,6 +1344,7 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
     list_complete = next0 >= src_count;
     forms_ready = pretest && list_complete;
   }
+  if constexpr (RNG_LATE) load_rng();
   tl_mark(1);                                                      // family + classification done
   float4 sure_col = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   if constexpr (BIN && ONEPASS) { if (sure_hit_tile) sure_col = p.tri_color[sure_winner]; }
@@ -1358,6 +1387,7 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
       best_i[k] = -1;
     }
 
+    const unsigned long long lanes_in = __builtin_amdgcn_ballot_w64(inside);   // (wave constant: hoisted)
     float dox[K], doy[K];                                           // PRETEST: each ray's lens offset do = o - oc
     float dFx = 0.0f, dFy = 0.0f, dFz = 0.0f;                       // PRETEST: this lane's focal point minus the tile's box centre
     if constexpr (PRETEST) {
@@ -1384,27 +1414,26 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
             // per-sample forms of this candidate at each ray's own lens origin: does ANY ray of the wave survive?
             const float4 f0 = cP[4u * j], f1 = cP[4u * j + 1u], q2 = cP[4u * j + 2u], q3 = cP[4u * j + 3u];
             const float f2 = q2.x;
-            // gradients: bf16 pairs, unpacked with one VALU op each (no detour over the scalar unit:
-            // readfirstlane + s_and/s_lshl measured slower, the loop is latency-sensitive)
-            auto hi16 = [](uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); };
-            auto lo16 = [](uint32_t w) { return __builtin_bit_cast(float, w << 16); };
-            const uint32_t w0 = __builtin_bit_cast(uint32_t, q2.y), w1 = __builtin_bit_cast(uint32_t, q2.z),
-                           w2 = __builtin_bit_cast(uint32_t, q2.w), w3 = __builtin_bit_cast(uint32_t, q3.x),
-                           w4 = __builtin_bit_cast(uint32_t, q3.y);
+            // gradients: fp16 pairs read in place by v_fma_mix_f32 (op_sel picks the half): no unpack instructions
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            const h2 w0 = __builtin_bit_cast(h2, q2.y), w1 = __builtin_bit_cast(h2, q2.z), w2 = __builtin_bit_cast(h2, q2.w),
+                     w3 = __builtin_bit_cast(h2, q3.x), w4 = __builtin_bit_cast(h2, q3.y);      // .y = high half
             // per lane and candidate: constant term + gradient . (this lane's focal point - box centre)
-            const float b1 = __builtin_fmaf(hi16(w1), dFz, __builtin_fmaf(lo16(w0), dFy, __builtin_fmaf(hi16(w0), dFx, f0.x)));
-            const float b2 = __builtin_fmaf(lo16(w2), dFz, __builtin_fmaf(hi16(w2), dFy, __builtin_fmaf(lo16(w1), dFx, f0.w)));
-            const float b3 = __builtin_fmaf(hi16(w4), dFz, __builtin_fmaf(lo16(w3), dFy, __builtin_fmaf(hi16(w3), dFx, f1.z)));
-            unsigned long long alive = 0ull;
+            const float b1 = __builtin_fmaf(static_cast<float>(w1.y), dFz, __builtin_fmaf(static_cast<float>(w0.x), dFy, __builtin_fmaf(static_cast<float>(w0.y), dFx, f0.x)));
+            const float b2 = __builtin_fmaf(static_cast<float>(w2.x), dFz, __builtin_fmaf(static_cast<float>(w2.y), dFy, __builtin_fmaf(static_cast<float>(w1.x), dFx, f0.w)));
+            const float b3 = __builtin_fmaf(static_cast<float>(w4.y), dFz, __builtin_fmaf(static_cast<float>(w3.x), dFy, __builtin_fmaf(static_cast<float>(w3.y), dFx, f1.z)));
+            // a ray is skipped when its smallest form is negative; the candidate when that holds for every ray of the wave:
+            // per sample one compare, the lane masks combined on the scalar unit (a NaN form never skips: NaN < 0 is false)
+            unsigned long long all_neg = ~0ull;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
               const float F1 = __builtin_fmaf(f0.z, doy[k], __builtin_fmaf(f0.y, dox[k], b1));
               const float F2 = __builtin_fmaf(f1.y, doy[k], __builtin_fmaf(f1.x, dox[k], b2));
               const float F3 = __builtin_fmaf(f2, doy[k], __builtin_fmaf(f1.w, dox[k], b3));
               const float worst = __builtin_fminf(__builtin_fminf(F1, F2), F3);
-              alive |= __builtin_amdgcn_ballot_w64(!(worst < 0.0f) && inside && static_cast<uint32_t>(k) < valid_k);
+              all_neg &= __builtin_amdgcn_ballot_w64(worst < 0.0f) | ((static_cast<uint32_t>(k) < valid_k) ? 0ull : ~0ull);
             }
-            if (alive == 0ull) { if constexpr (STATS) st_pre += 1; continue; }
+            if ((~all_neg & lanes_in) == 0ull) { if constexpr (STATS) st_pre += 1; continue; }
           }
           const float4 A0 = cA[2u * j], A1 = cA[2u * j + 1u];
           test_triangle<FMA, K, FILTER, STATS>(A0, A1, [&] { return cB[j]; }, cI[j], o, d, best_t, best_i,
