@@ -1409,35 +1409,53 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
           next = classify(base, std::false_type{});
           if (base == 0u && next >= src_count) list_complete = true;     // (!PRE: the first classification happens here)
         }
-        for (uint32_t j = 0; j < list_count; ++j) {                // ascending triangle order
-          if (forms_ready) {
-            // per-sample forms of this candidate at each ray's own lens origin: does ANY ray of the wave survive?
-            const float4 f0 = cP[4u * j], f1 = cP[4u * j + 1u], q2 = cP[4u * j + 2u], q3 = cP[4u * j + 3u];
-            const float f2 = q2.x;
-            // gradients: fp16 pairs read in place by v_fma_mix_f32 (op_sel picks the half): no unpack instructions
-            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-            const h2 w0 = __builtin_bit_cast(h2, q2.y), w1 = __builtin_bit_cast(h2, q2.z), w2 = __builtin_bit_cast(h2, q2.w),
-                     w3 = __builtin_bit_cast(h2, q3.x), w4 = __builtin_bit_cast(h2, q3.y);      // .y = high half
-            // per lane and candidate: constant term + gradient . (this lane's focal point - box centre)
-            const float b1 = __builtin_fmaf(static_cast<float>(w1.y), dFz, __builtin_fmaf(static_cast<float>(w0.x), dFy, __builtin_fmaf(static_cast<float>(w0.y), dFx, f0.x)));
-            const float b2 = __builtin_fmaf(static_cast<float>(w2.x), dFz, __builtin_fmaf(static_cast<float>(w2.y), dFy, __builtin_fmaf(static_cast<float>(w1.x), dFx, f0.w)));
-            const float b3 = __builtin_fmaf(static_cast<float>(w4.y), dFz, __builtin_fmaf(static_cast<float>(w3.x), dFy, __builtin_fmaf(static_cast<float>(w3.y), dFx, f1.z)));
-            // a ray is skipped when its smallest form is negative; the candidate when that holds for every ray of the wave:
-            // per sample one compare, the lane masks combined on the scalar unit (a NaN form never skips: NaN < 0 is false)
-            unsigned long long all_neg = ~0ull;
+        // does ANY ray of the wave survive the per-sample forms of candidate j?  (wave-uniform)
+        auto forms_alive = [&](uint32_t j) -> bool {
+          // per-sample forms of this candidate at each ray's own lens origin: does ANY ray of the wave survive?
+          const float4 f0 = cP[4u * j], f1 = cP[4u * j + 1u], q2 = cP[4u * j + 2u], q3 = cP[4u * j + 3u];
+          const float f2 = q2.x;
+          // gradients: fp16 pairs read in place by v_fma_mix_f32 (op_sel picks the half): no unpack instructions
+          typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+          const h2 w0 = __builtin_bit_cast(h2, q2.y), w1 = __builtin_bit_cast(h2, q2.z), w2 = __builtin_bit_cast(h2, q2.w),
+                   w3 = __builtin_bit_cast(h2, q3.x), w4 = __builtin_bit_cast(h2, q3.y);      // .y = high half
+          // per lane and candidate: constant term + gradient . (this lane's focal point - box centre)
+          const float b1 = __builtin_fmaf(static_cast<float>(w1.y), dFz, __builtin_fmaf(static_cast<float>(w0.x), dFy, __builtin_fmaf(static_cast<float>(w0.y), dFx, f0.x)));
+          const float b2 = __builtin_fmaf(static_cast<float>(w2.x), dFz, __builtin_fmaf(static_cast<float>(w2.y), dFy, __builtin_fmaf(static_cast<float>(w1.x), dFx, f0.w)));
+          const float b3 = __builtin_fmaf(static_cast<float>(w4.y), dFz, __builtin_fmaf(static_cast<float>(w3.x), dFy, __builtin_fmaf(static_cast<float>(w3.y), dFx, f1.z)));
+          // a ray is skipped when its smallest form is negative; the candidate when that holds for every ray of the wave:
+          // per sample one compare, the lane masks combined on the scalar unit (a NaN form never skips: NaN < 0 is false)
+          unsigned long long all_neg = ~0ull;
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-              const float F1 = __builtin_fmaf(f0.z, doy[k], __builtin_fmaf(f0.y, dox[k], b1));
-              const float F2 = __builtin_fmaf(f1.y, doy[k], __builtin_fmaf(f1.x, dox[k], b2));
-              const float F3 = __builtin_fmaf(f2, doy[k], __builtin_fmaf(f1.w, dox[k], b3));
-              const float worst = __builtin_fminf(__builtin_fminf(F1, F2), F3);
-              all_neg &= __builtin_amdgcn_ballot_w64(worst < 0.0f) | ((static_cast<uint32_t>(k) < valid_k) ? 0ull : ~0ull);
-            }
-            if ((~all_neg & lanes_in) == 0ull) { if constexpr (STATS) st_pre += 1; continue; }
+          for (int k = 0; k < K; ++k) {
+            const float F1 = __builtin_fmaf(f0.z, doy[k], __builtin_fmaf(f0.y, dox[k], b1));
+            const float F2 = __builtin_fmaf(f1.y, doy[k], __builtin_fmaf(f1.x, dox[k], b2));
+            const float F3 = __builtin_fmaf(f2, doy[k], __builtin_fmaf(f1.w, dox[k], b3));
+            const float worst = __builtin_fminf(__builtin_fminf(F1, F2), F3);
+            all_neg &= __builtin_amdgcn_ballot_w64(worst < 0.0f) | ((static_cast<uint32_t>(k) < valid_k) ? 0ull : ~0ull);
           }
+          const bool alive = (~all_neg & lanes_in) != 0ull;
+          if constexpr (STATS) { if (!alive) st_pre += 1; }
+          return alive;
+        };
+        auto run_tests = [&](uint32_t j) {
           const float4 A0 = cA[2u * j], A1 = cA[2u * j + 1u];
           test_triangle<FMA, K, FILTER, STATS>(A0, A1, [&] { return cB[j]; }, cI[j], o, d, best_t, best_i,
                                                nearest, inside, valid_k, st_exit, st_skip);
+        };
+        if (forms_ready) {
+          // Two candidates per trip: both records are requested before either form is evaluated, so that a wave waits for
+          // LDS once per pair -- the loop is latency-bound at 4 waves per SIMD: C4 4.64 -> 4.15 ms.  (Written out: the same
+          // loop as a generic group of N with a flag array measured 4.39 / 4.42 / 4.43 ms for N = 2 / 3 / 4.)  The exact
+          // tests stay in ascending order.
+          uint32_t j = 0;
+          for (; j + 1u < list_count; j += 2u) {
+            const bool a0 = forms_alive(j), a1 = forms_alive(j + 1u);
+            if (a0) run_tests(j);
+            if (a1) run_tests(j + 1u);
+          }
+          if (j < list_count && forms_alive(j)) run_tests(j);
+        } else {
+          for (uint32_t j = 0; j < list_count; ++j) run_tests(j);   // ascending triangle order
         }
         base = next;
         if (!list_complete) __builtin_amdgcn_wave_barrier();       // list is rewritten by the next round
