@@ -83,7 +83,13 @@ typedef struct rt_options {
   uint32_t samples_in_flight;  /* samples of a pixel kept in registers per pass (1,2,4; 0 = auto) */
   uint32_t lds_chunk;          /* full-scan path: triangles staged in LDS at a time (0 = auto) */
   uint32_t bin_list;           /* binned path: candidate records per wave in LDS (0 = auto; multiple of 64) */
+  uint32_t transport;          /* rt_tracer_create_multi: RT_TRANSPORT_RCCL (default) | RT_TRANSPORT_PEER */
 } rt_options;
+
+#define RT_TRANSPORT_RCCL  0u  /* finished tiles travel to the root with grouped ncclSend / ncclRecv (RCCL over xGMI) */
+#define RT_TRANSPORT_PEER  1u  /* one process only: the bands' trace kernels store their BGRA8 tiles straight into the root's frame
+                                  through a peer mapping (hipDeviceEnablePeerAccess): no collective, no kernels on the root.  Falls
+                                  back to RCCL, with the reason in rt_tracer_group_info, when a device may not map the root's memory */
 
 /* ---- the reference's public methods, one to one -------------------------------------- */
 
@@ -265,6 +271,12 @@ int  rt_tracer_set_band(rt_tracer* t, uint32_t row_begin, uint32_t rows);
 /* Device time of the gathers since the last reset (root only; HIP events on the root's gather stream around
  * the exchange) and their number.  Zero for a frame whose bands all live on the root device. */
 int  rt_tracer_gather_time(rt_tracer* t, double* total_ms, uint64_t* gathers, int reset_after);
+/* One more exchange of the tiles as they are, without tracing: what the gather costs on its own (read it with
+ * rt_tracer_gather_time).  A multi-device tracer or a group member (collective: every rank calls it). */
+int  rt_tracer_gather_only(rt_tracer* t);
+/* What the group is made of, as JSON text: transport ("rccl" | "peer" | "local" | "none"), ranks, the band -> rank map, the local
+ * devices, and for an RCCL transport the library's version and per communicator its rank, ncclCommCount and device. */
+int  rt_tracer_group_info(rt_tracer* t, char* json, size_t capacity);
 /* Bands of the handle (1 for a plain tracer) and where band k runs: out = {device, first row, rows, rank}. */
 int  rt_tracer_band_count(rt_tracer* t);
 int  rt_tracer_band_info(rt_tracer* t, uint32_t band, uint32_t out[4]);

@@ -26,6 +26,7 @@ FLAG_NO_MACRO_BINS = 16
 FLAG_NO_SURE_HIT = 32
 BUF_RENDER, BUF_COUNTS, BUF_IMAGE, BUF_RNG, BUF_FRAME = 0, 1, 2, 3, 4
 GROUP_ID_BYTES = 128
+TRANSPORT_RCCL, TRANSPORT_PEER = 0, 1
 
 # every symbol include/rt_mi355x.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -44,6 +45,7 @@ ABI_SYMBOLS = [
     "rt_tracer_create_multi", "rt_group_unique_id", "rt_tracer_join_group", "rt_tracer_leave_group",
     "rt_tracer_gather_time", "rt_tracer_band_count", "rt_tracer_band_info",
     "rt_tracer_join_group_bands", "rt_balance_rows", "rt_tracer_rebalance", "rt_tracer_set_band", "rt_dbg_read_tile_lists", "rt_dbg_focal_boxes", "rt_dbg_classify",
+    "rt_tracer_gather_only", "rt_tracer_group_info",
 ]
 
 
@@ -55,7 +57,7 @@ class Options(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("full_height", C.c_uint32),
                 ("row_begin", C.c_uint32), ("use_time_seed", C.c_uint32), ("math_mode", C.c_uint32),
                 ("seed", C.c_uint64), ("flags", C.c_uint32), ("samples_in_flight", C.c_uint32),
-                ("lds_chunk", C.c_uint32), ("bin_list", C.c_uint32)]
+                ("lds_chunk", C.c_uint32), ("bin_list", C.c_uint32), ("transport", C.c_uint32)]
 
 
 CALLBACK = C.CFUNCTYPE(None, C.POINTER(C.c_uint32), C.c_size_t, C.c_void_p)
@@ -183,6 +185,8 @@ def load_library():
         L.rt_tracer_set_band.argtypes = [vp, C.c_uint32, C.c_uint32]
         L.rt_dbg_read_tile_lists.argtypes = [vp, u32p, C.c_size_t, u32p]
         L.rt_dbg_focal_boxes.argtypes = [vp, C.c_float, f32p, C.c_size_t, f32p, C.c_size_t]
+        L.rt_tracer_gather_only.argtypes = [vp]
+        L.rt_tracer_group_info.argtypes = [vp, C.c_char_p, C.c_size_t]
         L.rt_dbg_classify.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, u32p, C.c_uint32, f32p, C.c_size_t]
         _lib = L
         return _lib
@@ -229,7 +233,7 @@ class RayTracer:
     def __init__(self, imageSize, cameraPosition=(0.0, 0.0, 0.0), cameraAngles=(0.0, 0.0), fov=70.0,
                  focalLength=10.0, aperture=4.0, *, seed=None, device=0, math_mode=MATH_FMA,
                  full_height=0, row_begin=0, no_filter=False, no_binning=False, nearest_hit=False, smooth_normals=False, no_macro_bins=False, samples_in_flight=0,
-                 lds_chunk=0, bin_list=0, devices=None, no_sure_hit=False):
+                 lds_chunk=0, bin_list=0, devices=None, no_sure_hit=False, transport="rccl"):
         """devices: a list of HIP device ordinals, one per row band -> the frame is sharded over them inside
         this process (rt_tracer_create_multi; ordinals may repeat); None -> one tracer on `device`."""
         self._lib = load_library()
@@ -248,6 +252,7 @@ class RayTracer:
                      (FLAG_NEAREST_HIT if nearest_hit else 0) | (FLAG_SMOOTH_NORMALS if smooth_normals else 0) | (FLAG_NO_MACRO_BINS if no_macro_bins else 0) |
                      (FLAG_NO_SURE_HIT if no_sure_hit else 0))
         opt.samples_in_flight, opt.lds_chunk, opt.bin_list = samples_in_flight, lds_chunk, bin_list
+        opt.transport = {"rccl": TRANSPORT_RCCL, "peer": TRANSPORT_PEER}[transport]
         if devices is not None:
             devs = np.ascontiguousarray(devices, np.int32)
             rc = self._lib.rt_tracer_create_multi(_u32p(size), _f32p(np.array(cameraPosition, np.float32)),
@@ -421,6 +426,17 @@ class RayTracer:
         ms, n = C.c_double(), C.c_uint64()
         self._lib.rt_tracer_gather_time(self._h, C.byref(ms), C.byref(n), 1 if reset else 0)
         return ms.value, n.value
+
+    def GatherOnly(self):
+        """One more exchange of the tiles as they are, no tracing (collective in a multi-process group)."""
+        self._check(self._lib.rt_tracer_gather_only(self._h))
+
+    def GroupInfo(self):
+        """dict: transport, ranks, band -> rank map, local devices, RCCL version and communicators (rt_tracer_group_info)."""
+        import json
+        buf = C.create_string_buffer(8192)
+        self._check(self._lib.rt_tracer_group_info(self._h, buf, len(buf)))
+        return json.loads(buf.value.decode())
 
     def Bands(self):
         """[{device, row0, rows, rank}] of the handle's bands (one entry for a plain tracer)."""

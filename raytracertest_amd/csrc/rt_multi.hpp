@@ -67,6 +67,12 @@ struct Group {
   std::vector<GatherRank> local;    // ranks of this process; the root (rank 0), when local, is local[0]
   bool has_root = false;
   bool self_rccl = false;           // RT_MI355X_GATHER_SELF=1: root-local bands travel through RCCL too (1-GPU rehearsal of the call sequence)
+  // Peer transport (rt_options.transport = RT_TRANSPORT_PEER, one process only): every band's emitting launch writes its
+  // BGRA8 tile straight into its rows of the ROOT's frame buffer through a peer mapping (hipDeviceEnablePeerAccess) --
+  // posted xGMI writes spread over the kernel's lifetime, no send buffers, no collective, no receive kernels on the root's
+  // CUs; the "gather" is the root's gather stream waiting for every band's event.  peer_note: why it was not granted.
+  bool peer = false;
+  std::string peer_note;
   uint32_t* d_frame[2] = {nullptr, nullptr};   // root: the gathered frames
   hipEvent_t frame_done[2] = {nullptr, nullptr};   // root: frame b is complete (gather stream)
   hipEvent_t frame_free[2] = {nullptr, nullptr};   // root: the consumer of frame b (host copy) has finished
@@ -85,7 +91,7 @@ struct Group {
     for (GatherRank& r : local) if (r.rank == rank) return &r;
     return nullptr;
   }
-  bool travels(const GroupBand& b) const { return b.rank != 0 || self_rccl; }
+  bool travels(const GroupBand& b) const { return !peer && (b.rank != 0 || self_rccl); }
   size_t frame_bytes() const { return static_cast<size_t>(W) * H * sizeof(uint32_t); }
 
   // Device-side resources for the current geometry (bands[] filled in, local[] with rank/device/comm).
@@ -187,7 +193,8 @@ struct Group {
     for (GatherRank& r : local) {
       HIP_CHECK(hipSetDevice(r.device));
       for (GroupBand& band : bands)
-        if (band.tracer && band.rank == r.rank) HIP_CHECK(hipStreamWaitEvent(r.gstream, band.ready, 0));
+        if (band.tracer && (band.rank == r.rank || (peer && r.rank == 0)))   // peer: the root waits for every band's stores
+          HIP_CHECK(hipStreamWaitEvent(r.gstream, band.ready, 0));
     }
     bool any = false;
     for (const GroupBand& band : bands) any = any || travels(band);

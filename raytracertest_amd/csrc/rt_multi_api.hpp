@@ -257,7 +257,33 @@ int multi_create(const uint32_t imageSize[2], const float cameraPosition[3], con
       r.rank = static_cast<int>(d); r.device = m->devices[d];
       g.local.push_back(r);
     }
-    if (g.n_ranks > 1 || g.self_rccl) {                                // one communicator per device (single-process clique)
+    // transport: peer stores into the root's frame when asked for and every device may map the root's memory
+    const char* tenv = getenv("RT_MI355X_TRANSPORT");
+    const bool want_peer = (opt.transport == RT_TRANSPORT_PEER || (tenv && strcmp(tenv, "peer") == 0)) && !(tenv && strcmp(tenv, "rccl") == 0);
+    if (want_peer && !g.self_rccl) {
+      g.peer = true;
+      for (size_t d = 1; d < m->devices.size() && g.peer; ++d) {
+        int can = 0;
+        const hipError_t e = hipDeviceCanAccessPeer(&can, m->devices[d], m->devices[0]);
+        if (env_on("RT_MI355X_PEER_DENY")) can = 0;                  // (tests: the fallback path on any box)
+        if (e != hipSuccess || !can) {
+          g.peer = false;
+          g.peer_note = fmt("device %d cannot map the memory of root device %d (%s): falling back to the RCCL gather", m->devices[d],
+                            m->devices[0], e != hipSuccess ? hipGetErrorString(e) : "hipDeviceCanAccessPeer = 0");
+        }
+      }
+      if (m->devices.size() == 1 && env_on("RT_MI355X_PEER_DENY")) { g.peer = false; g.peer_note = "peer access denied (RT_MI355X_PEER_DENY): falling back to the RCCL gather"; }
+      for (size_t d = 1; d < m->devices.size() && g.peer; ++d) {
+        HIP_CHECK(hipSetDevice(m->devices[d]));
+        const hipError_t e = hipDeviceEnablePeerAccess(m->devices[0], 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+          g.peer = false;
+          g.peer_note = fmt("hipDeviceEnablePeerAccess(%d -> %d): %s: falling back to the RCCL gather", m->devices[d], m->devices[0], hipGetErrorString(e));
+        }
+        (void)hipGetLastError();
+      }
+    }
+    if ((g.n_ranks > 1 && !g.peer) || g.self_rccl) {                   // one communicator per device (single-process clique)
       rtc::Rccl& nccl = need_rccl();
       std::vector<ncclComm_t> comms(m->devices.size(), nullptr);
       RCCL_CHECK(nccl.CommInitAll(comms.data(), static_cast<int>(m->devices.size()), m->devices.data()));
@@ -326,6 +352,73 @@ void balance_rows(uint32_t n, const uint32_t* begins, const double* cost, uint32
     const uint32_t hi = H - (n - k) * granule;                         // ... also for the bands behind
     out[k] = r < lo ? lo : r > hi ? hi : r;
   }
+}
+
+size_t member_band_index(rt_tracer* t);
+
+// The tiles as they are, gathered once more (no tracing): what one exchange costs on its own -- rt_tracer_gather_time reads
+// the device time.  Collective in a multi-process group.
+void group_gather_only(rt_tracer* t) {
+  if (t->mg) {
+    MultiState& m = *t->mg;
+    Group& g = m.group;
+    const int b = g.begin_frame();
+    m.for_bands([&](size_t k) {
+      m.bands[k]->use_device();
+      (void)g.tile_target(k, b);                                       // (orders the band's streams behind the buffer's last reader)
+      g.tile_written(k);
+    });
+    g.gather(b);
+    return;
+  }
+  Group& g = *t->grp;
+  const int b = g.begin_frame();
+  const size_t k = member_band_index(t);
+  t->use_device();
+  (void)g.tile_target(k, b);
+  g.tile_written(k);
+  g.gather(b);
+}
+
+// what the group is made of, as JSON text (reporting: bench.py, tests)
+std::string group_info_json(rt_tracer* t) {
+  Group* g = t->mg ? &t->mg->group : t->grp;
+  if (!g) return "{\"transport\": \"none\", \"ranks\": 1, \"note\": \"a single tracer: nothing to gather\"}";
+  rtc::Rccl& nccl = rtc::Rccl::get();
+  bool any_travel = false;
+  for (const GroupBand& b : g->bands) any_travel = any_travel || g->travels(b);
+  const char* transport = g->peer ? "peer" : (any_travel ? "rccl" : "local");
+  std::string s = fmt("{\"transport\": \"%s\", \"ranks\": %d, \"bands\": %zu", transport, g->n_ranks, g->bands.size());
+  s += ", \"note\": \"";
+  s += g->peer ? "every band stores its BGRA8 tile into the root's frame through a peer mapping; no collective"
+               : (any_travel ? "grouped ncclSend / ncclRecv of the BGRA8 tiles to rank 0" : "every band lives on the root device: tiles are written in place");
+  if (!g->peer_note.empty()) { s += "; "; s += g->peer_note; }
+  s += "\"";
+  s += ", \"band_ranks\": [";
+  for (size_t k = 0; k < g->bands.size(); ++k) s += fmt("%s%d", k ? ", " : "", g->bands[k].rank);
+  s += "], \"local_devices\": [";
+  for (size_t k = 0; k < g->local.size(); ++k) s += fmt("%s%d", k ? ", " : "", g->local[k].device);
+  s += "]";
+  bool have_comm = false;
+  for (const GatherRank& r : g->local) have_comm = have_comm || r.comm != nullptr;
+  if (have_comm && nccl.ok()) {
+    int ver = 0;
+    if (nccl.GetVersion && nccl.GetVersion(&ver) == ncclSuccess) s += fmt(", \"rccl_version\": %d", ver);
+    s += fmt(", \"rccl_library\": \"%s\", \"communicators\": [", nccl.path.c_str());
+    bool first = true;
+    for (const GatherRank& r : g->local) {
+      if (!r.comm) continue;
+      int count = -1, dev = -1, rank = -1;
+      if (nccl.CommCount) (void)nccl.CommCount(r.comm, &count);
+      if (nccl.CommCuDevice) (void)nccl.CommCuDevice(r.comm, &dev);
+      if (nccl.CommUserRank) (void)nccl.CommUserRank(r.comm, &rank);
+      s += fmt("%s{\"rank\": %d, \"ranks_in_communicator\": %d, \"device\": %d}", first ? "" : ", ", rank, count, dev);
+      first = false;
+    }
+    s += "]";
+  }
+  s += "}";
+  return s;
 }
 
 // whole-frame view of the per-band buffers (parity tests, host read-back)

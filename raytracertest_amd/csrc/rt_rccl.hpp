@@ -25,6 +25,10 @@ struct Rccl {
   decltype(&ncclSend) Send = nullptr;
   decltype(&ncclRecv) Recv = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclGetVersion) GetVersion = nullptr;          // optional (reporting only)
+  decltype(&ncclCommCount) CommCount = nullptr;
+  decltype(&ncclCommCuDevice) CommCuDevice = nullptr;
+  decltype(&ncclCommUserRank) CommUserRank = nullptr;
   void* handle = nullptr;
   std::string why;        // why loading failed
   std::string path;       // what was loaded
@@ -64,7 +68,11 @@ struct Rccl {
                      sym(CommInitAll, "ncclCommInitAll") && sym(CommDestroy, "ncclCommDestroy") &&
                      sym(GroupStart, "ncclGroupStart") && sym(GroupEnd, "ncclGroupEnd") && sym(Send, "ncclSend") &&
                      sym(Recv, "ncclRecv") && sym(GetErrorString, "ncclGetErrorString");
-    if (!all) handle = nullptr;
+    if (!all) { handle = nullptr; return; }
+    GetVersion = reinterpret_cast<decltype(GetVersion)>(dlsym(handle, "ncclGetVersion"));
+    CommCount = reinterpret_cast<decltype(CommCount)>(dlsym(handle, "ncclCommCount"));
+    CommCuDevice = reinterpret_cast<decltype(CommCuDevice)>(dlsym(handle, "ncclCommCuDevice"));
+    CommUserRank = reinterpret_cast<decltype(CommUserRank)>(dlsym(handle, "ncclCommUserRank"));
   }
 };
 

@@ -1572,6 +1572,23 @@ int rt_tracer_gather_time(rt_tracer* t, double* total_ms, uint64_t* gathers, int
   return RT_OK;
 }
 
+int rt_tracer_gather_only(rt_tracer* t) {
+  if (!t || (!t->mg && !t->grp)) return RT_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(t->api_mu);
+  return guarded(t, [&] {
+    t->cancel_and_join();
+    group_gather_only(t);
+  });
+}
+
+int rt_tracer_group_info(rt_tracer* t, char* json, size_t capacity) {
+  if (!t || !json || capacity == 0) return RT_ERR_INVALID;
+  const std::string s = group_info_json(t);
+  if (s.size() + 1 > capacity) return RT_ERR_INVALID;
+  memcpy(json, s.c_str(), s.size() + 1);
+  return RT_OK;
+}
+
 int rt_tracer_band_count(rt_tracer* t) {
   if (!t) return 0;
   return t->mg ? static_cast<int>(t->mg->bands.size()) : 1;

@@ -43,8 +43,8 @@ def test_no_cpu_fallback_without_device():
 
 def test_options_struct_layout_matches_header():
     from raytracertest_amd import api
-    assert ctypes.sizeof(api.Options) == 48
-    assert api.Options.seed.offset == 24 and api.Options.flags.offset == 32
+    assert ctypes.sizeof(api.Options) == 56                  # (48 up to round 2: `transport` was appended; struct_size versions it)
+    assert api.Options.seed.offset == 24 and api.Options.flags.offset == 32 and api.Options.transport.offset == 48
 
 
 def test_product_does_not_touch_the_oracle():

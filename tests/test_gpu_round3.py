@@ -101,3 +101,75 @@ def test_certain_winner_tiles_in_a_200_triangle_scene(rt, orc, mode):
     assert int(sure[:, :W // 8].sum()) == st["tiles_by_list"]["sure"]
     assert ((winner[sure] >= 100) & (winner[sure] < 132)).all()       # the winners are walls / box faces of the Cornell part
     g.close(); h.close()
+
+
+# ------------------------------------------------------------------ the frame sharded over devices: transports
+def _multi_pair(rt, orc, W, H, devices, transport):
+    from raytracertest_amd import scenes
+    g = rt.RayTracer((W, H), (0, 0, 0), (0.0, 0.0), 70.0, 3.0, 0.05, seed=3, devices=devices, transport=transport)
+    o = orc.OracleTracer(W, H, (0.0, 0.0), 70.0, 3.0, 0.05, seed=3, contract=1, nthreads=8)
+    scn = scenes.cornell32()
+    assert g.UploadScene(scn) and o.upload_scene(scn)
+    return g, o
+
+
+@pytest.mark.parametrize("transport", ["rccl", "peer"])
+def test_transports_with_every_band_on_one_device(rt, orc, transport, monkeypatch):
+    """Both transports of rt_tracer_create_multi with three bands on device 0 == oracle (buffers and gathered frame), the group
+    says what it is made of, a gather without tracing runs; a denied peer mapping (RT_MI355X_PEER_DENY=1) falls back with the
+    reason on record.  (One device: nothing travels -- the multi-device forms are the tests below, skipped here.)"""
+    g, o = _multi_pair(rt, orc, 96, 50, [0, 0, 0], transport)
+    info = g.GroupInfo()
+    assert info["transport"] == ("peer" if transport == "peer" else "local") and info["bands"] == 3 and info["band_ranks"] == [0, 0, 0], info
+    g.Trace(2, 3, 0); assert g.Wait()
+    o.trace(2, 3)
+    assert np.array_equal(g.RenderBuffer().view(np.uint32), o.render.view(np.uint32)) and np.array_equal(g.Frame(), o.image)
+    for _ in range(3):
+        g.TraceEnqueue(1, 4); o.trace(1, 4)
+    g.GatherOnly(); g.Sync()
+    assert np.array_equal(g.Frame(), o.image)
+    g.close()
+    if transport == "peer":
+        monkeypatch.setenv("RT_MI355X_PEER_DENY", "1")
+        g, o = _multi_pair(rt, orc, 64, 40, [0, 0], "peer")
+        info = g.GroupInfo()
+        assert info["transport"] == "local" and "falling back to the RCCL gather" in info["note"], info
+        g.Trace(1, 2, 0); assert g.Wait()
+        o.trace(1, 2)
+        assert np.array_equal(g.Frame(), o.image)
+        g.close()
+
+
+@pytest.mark.parametrize("transport", ["rccl", "peer"])
+def test_transports_between_two_devices(rt, orc, transport):
+    """the gather between DEVICES.  Four bands on two GPUs in one process (rt_tracer_create_multi): RCCL
+    (ncclCommInitAll, grouped ncclSend / ncclRecv) and peer stores into the root's frame, each == the oracle's whole frame."""
+    if rt.device_count() < 2:
+        pytest.skip("needs at least two GPUs (the pool's boxes have one): run on a multi-GPU node")
+    g, o = _multi_pair(rt, orc, 160, 150, [0, 1, 0, 1], transport)
+    info = g.GroupInfo()
+    assert info["ranks"] == 2 and info["transport"] in (transport, "rccl"), info
+    if info["transport"] == "rccl":
+        assert [c["ranks_in_communicator"] for c in info["communicators"]] == [2, 2], info
+    g.Trace(3, 2, 0); assert g.Wait()
+    o.trace(3, 2)
+    assert np.array_equal(g.RenderBuffer().view(np.uint32), o.render.view(np.uint32)) and np.array_equal(g.Frame(), o.image)
+    for _ in range(4):                                  # both frame buffers, sends double-buffered
+        g.TraceEnqueue(1, 3); o.trace(1, 3)
+    g.Sync()
+    assert np.array_equal(g.Frame(), o.image)
+    g.GatherOnly(); g.Sync()
+    assert np.array_equal(g.Frame(), o.image)
+    g.close()
+
+
+def test_one_process_per_gpu_through_the_native_exchange(rt):
+    """rt_tracer_join_group between processes (tests/dist_native.py: RowBandJob + NativeExchange, frame == oracle)."""
+    if rt.device_count() < 2:
+        pytest.skip("needs at least two GPUs (the pool's boxes have one): run on a multi-GPU node")
+    import os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "tests", "dist_native.py")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "dist_native ok: world=2" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
