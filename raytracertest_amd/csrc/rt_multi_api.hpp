@@ -362,8 +362,8 @@ void group_gather_only(rt_tracer* t) {
   if (t->mg) {
     MultiState& m = *t->mg;
     Group& g = m.group;
-    const int b = g.begin_frame();
-    m.for_bands([&](size_t k) {
+    const int b = g.last_b < 0 ? 0 : g.last_b;                         // the frame (and send buffers) the last launch wrote: tiles of
+    m.for_bands([&](size_t k) {                                        // root-local bands were stored in place, into that frame only
       m.bands[k]->use_device();
       (void)g.tile_target(k, b);                                       // (orders the band's streams behind the buffer's last reader)
       g.tile_written(k);
@@ -372,7 +372,7 @@ void group_gather_only(rt_tracer* t) {
     return;
   }
   Group& g = *t->grp;
-  const int b = g.begin_frame();
+  const int b = g.last_b < 0 ? 0 : g.last_b;
   const size_t k = member_band_index(t);
   t->use_device();
   (void)g.tile_target(k, b);
