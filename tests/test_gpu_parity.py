@@ -421,21 +421,23 @@ def test_fused_launch_argument_checks(rt):
 
 def test_image_mirror_receives_the_emitted_image(rt):
     """rt_tracer_set_image_mirror: the emitting launch writes the BGRA8 image into a caller-owned device
-    buffer too (what the multi-GPU step uses as the gather's send buffer)."""
-    import torch
+    buffer too (what the multi-GPU step uses as the gather's send buffer).  The caller-owned buffer here is the image
+    buffer of a second, idle tracer of the same size."""
     import raytracertest_amd as R
+    from raytracertest_amd.api import BUF_IMAGE
     W, H = 70, 37
     g = R.RayTracer((W, H), (0, 0, 0), (0.0, 0.0), 70.0, 3.0, 0.05, seed=3)
     g.UploadScene(scene("cornell"))
-    mirror = torch.zeros((H, W), dtype=torch.int32, device="cuda")
-    torch.cuda.synchronize()
-    g.SetImageMirror(mirror.data_ptr())
+    other = R.RayTracer((W, H), (0, 0, 0), (0.0, 0.0), 70.0, 3.0, 0.05, seed=4)
+    assert not other.Image().any()
+    g.SetImageMirror(other.DevicePointer(BUF_IMAGE))
     g.TraceEnqueue(3, 2); g.Sync()
-    assert np.array_equal(mirror.cpu().numpy().view(np.uint32), g.Image())
+    assert g.Image().any() and np.array_equal(other.Image(), g.Image())
     g.SetImageMirror(None)
-    before = mirror.clone()
+    before = other.Image()
     g.TraceEnqueue(1, 2); g.Sync()
-    assert torch.equal(before, mirror) and not np.array_equal(before.cpu().numpy().view(np.uint32), g.Image())
+    assert np.array_equal(before, other.Image()) and not np.array_equal(before, g.Image())
+    g.close(); other.close()
 
 
 def test_trace_enqueue_matches_trace(rt, orc):
@@ -595,31 +597,47 @@ def test_launch_building_block_and_progressive_driver(rt, orc):
     job.close()
 
 
+_INTEROP = r'''
+import sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+import raytracertest_amd as R
+from raytracertest_amd import scenes
+from raytracertest_amd.api import BUF_IMAGE
+g = R.RayTracer((96, 54), (0, 0, 0), (0, 0), 70.0, 3.0, 0.05, seed=1)
+g.UploadScene(scenes.cornell32())
+assert g.Stream() != 0
+ext = torch.cuda.ExternalStream(g.Stream(), device=torch.device("cuda", 0))
+tile = torch.zeros((54, 96), dtype=torch.int32, device="cuda")
+ev = torch.cuda.Event()
+for _ in range(3):
+    g.TraceEnqueue(1, 4)
+    g.CopyToDeviceAsync(BUF_IMAGE, tile.data_ptr(), tile.numel() * 4)
+    ev.record(ext)
+    torch.cuda.current_stream().wait_event(ev)
+    doubled = tile * 2                       # consumer on torch's stream
+torch.cuda.synchronize()
+g.Sync()
+img = g.Image()
+assert np.array_equal(tile.cpu().numpy().view(np.uint32), img)
+assert np.array_equal(doubled.cpu().numpy(), (img.view(np.int32) * 2))
+print("INTEROP_OK")
+'''
+
+
 def test_stream_interop_for_the_overlapped_gather(rt):
     """Stream interop for an external driver that orders its OWN device work behind the tracer (rt_tracer_stream):
     the tracer's HIP stream wrapped as a torch ExternalStream, an async copy ordered behind the trace, an
-    event making torch's stream wait for it.  (The library's own tile gather does the same with its gather streams.)"""
-    import torch
-    import raytracertest_amd as R
-    from raytracertest_amd import scenes
-    from raytracertest_amd.api import BUF_IMAGE
-    g = R.RayTracer((96, 54), (0, 0, 0), (0, 0), 70.0, 3.0, 0.05, seed=1)
-    g.UploadScene(scenes.cornell32())
-    assert g.Stream() != 0
-    ext = torch.cuda.ExternalStream(g.Stream(), device=torch.device("cuda", 0))
-    tile = torch.zeros((54, 96), dtype=torch.int32, device="cuda")
-    ev = torch.cuda.Event()
-    for _ in range(3):
-        g.TraceEnqueue(1, 4)
-        g.CopyToDeviceAsync(BUF_IMAGE, tile.data_ptr(), tile.numel() * 4)
-        ev.record(ext)
-        torch.cuda.current_stream().wait_event(ev)
-        doubled = tile * 2                       # consumer on torch's stream
-    torch.cuda.synchronize()
-    g.Sync()
-    img = g.Image()
-    assert np.array_equal(tile.cpu().numpy().view(np.uint32), img)
-    assert np.array_equal(doubled.cpu().numpy(), (img.view(np.int32) * 2))
+    event making torch's stream wait for it.  (The library's own tile gather does the same with its gather streams.)
+    In a process of its own: bringing torch.cuda up on a fresh box can take minutes (the image pages in), which must not
+    look like a hung GPU test; if it does not come up within four minutes the test is skipped, not failed."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        out = subprocess.run([sys.executable, "-c", _INTEROP % root], capture_output=True, text=True, timeout=240)
+    except subprocess.TimeoutExpired:
+        pytest.skip("torch.cuda did not come up within 240 s on this box")
+    assert out.returncode == 0 and "INTEROP_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
 def test_randomised_campaign_default_kernel_equals_plain_full_scan(rt):
