@@ -173,3 +173,35 @@ def test_one_process_per_gpu_through_the_native_exchange(rt):
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", str(port), os.path.join(root, "tests", "dist_native.py")], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "dist_native ok: world=2" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+
+
+def test_group_info_and_gather_only_through_rccl_on_one_rank(rt, orc, monkeypatch):
+    """RT_MI355X_GATHER_SELF=1 routes root-local tiles through the RCCL path on a one-rank communicator: the group reports
+    what RCCL itself says it spans (version, ncclCommCount, device), a gather without tracing re-delivers the last frame, and
+    a split launch's cost (rt_tracer_launch_time: to the end of the later half) is at least its upper half's kernel time."""
+    monkeypatch.setenv("RT_MI355X_GATHER_SELF", "1")
+    g, o = _multi_pair(rt, orc, 96, 300, [0, 0], "rccl")
+    info = g.GroupInfo()
+    assert info["transport"] == "rccl" and info["rccl_version"] > 0, info
+    assert info["communicators"] == [{"rank": 0, "ranks_in_communicator": 1, "device": 0}], info
+    for _ in range(3):
+        g.TraceEnqueue(1, 3); o.trace(1, 3)
+    g.Sync()
+    assert np.array_equal(g.Frame(), o.image)
+    g.GatherTime()
+    g.GatherOnly(); g.GatherOnly(); g.Sync()
+    ms, n = g.GatherTime()
+    assert n == 2 and ms > 0.0 and np.array_equal(g.Frame(), o.image)
+    g.close()
+    monkeypatch.delenv("RT_MI355X_GATHER_SELF")
+    h = rt.RayTracer((96, 300), (0, 0, 0), (0.0, 0.0), 70.0, 3.0, 0.05, seed=3)
+    from raytracertest_amd import scenes
+    h.UploadScene(scenes.cornell32())
+    h.KernelTime()
+    for _ in range(8):
+        h.TraceEnqueue(1, 8)                      # 300 rows: split launches
+    h.Sync()
+    span_ms, n1 = h.LaunchTime(reset=False)
+    k_ms, n2 = h.KernelTime()
+    assert n1 == n2 >= 2 and span_ms >= k_ms > 0.0
+    h.close()
