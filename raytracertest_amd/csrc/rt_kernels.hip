@@ -417,7 +417,7 @@ hipError_t launch_macro_bin(const TraceParams& p, bool fma, hipStream_t st) {
 hipError_t launch_tile_lists(const TraceParams& p, bool fma, hipStream_t st) {
   if (p.tile_lists == nullptr || p.rows == 0u || p.W == 0u) return hipSuccess;
   static const bool flat = [] { const char* e = getenv("RT_MI355X_LISTS_FLAT"); return e && e[0] == '1'; }();   // A/B: one-level build
-  if (p.tile_curv > 0.0f && !flat) {                                 // two levels: region -> tiles
+  if (p.tile_curv > 0.0f && !flat && p.n_tris <= 256u) {             // two levels: region -> tiles (its LDS candidate list holds 256)
     const dim3 grid(cdiv(cdiv(p.W, 32) * cdiv(cdiv(p.rows, 8), 2), 4u));
     if (fma) hipLaunchKernelGGL((region_lists_kernel<true>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((region_lists_kernel<false>), grid, dim3(256), 0, st, p);

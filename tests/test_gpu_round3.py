@@ -205,3 +205,24 @@ def test_group_info_and_gather_only_through_rccl_on_one_rank(rt, orc, monkeypatc
     k_ms, n2 = h.KernelTime()
     assert n1 == n2 >= 2 and span_ms >= k_ms > 0.0
     h.close()
+
+
+def test_small_scene_path_with_an_explicit_long_list(rt, orc):
+    """rt_options.bin_list = 320 makes a 300-triangle scene a small scene (one list per tile, built ahead of the launch): more
+    triangles than the two-level builder's region list holds, so the one-level builder serves it -- five classification steps
+    per tile, the certain-winner verdict carried across them.  == oracle, through Trace and split TraceEnqueue launches."""
+    from raytracertest_amd import scenes
+    scn = np.concatenate([scenes.random_triangles(268, 99), scenes.cornell32()])
+    W, H = 128, 136
+    g = rt.RayTracer((W, H), (0, 0, 0), (0.0, 0.0), 70.0, 3.0, 0.03, seed=2, bin_list=320)
+    o = orc.OracleTracer(W, H, (0.0, 0.0), 70.0, 3.0, 0.03, seed=2, contract=1, nthreads=8)
+    assert g.UploadScene(scn) and o.upload_scene(scn)
+    g.Trace(3, 2, 0); assert g.Wait()
+    o.trace(3, 2)
+    assert np.array_equal(g.RenderBuffer().view(np.uint32), o.render.view(np.uint32)) and np.array_equal(g.Image(), o.image)
+    g.TraceEnqueue(2, 3); g.Sync()
+    o.trace(2, 3)
+    assert np.array_equal(g.RenderBuffer().view(np.uint32), o.render.view(np.uint32)) and np.array_equal(g.RngStates(), o.rng)
+    count, winner, sure = g.DebugTileLists()
+    assert 0 < count.max() <= 300 and (winner[sure] < 300).all()
+    g.close()
