@@ -124,7 +124,6 @@ for name, i, t in (("C3", i3, t3), ("C4", i4, t4)):
         print("%s: VALU wave-instructions/launch %d = %.1f lane-instructions per ray; by kernel %s" % (name, i["valu_wave_instructions_per_launch"], i["lane_instructions_per_ray"], i["by_kernel"]))
     if t:
         print("%s: traffic %d B/launch = %.3f x algorithmic (%d)" % (name, t["bytes_per_launch"], t["bytes_per_launch"] / t["algorithmic_bytes_per_launch"], t["algorithmic_bytes_per_launch"]))
-# overlap of the two half-frame kernels of a launch, from the kernel trace of the --stats pass
-subprocess.run([sys.executable, os.path.join(root, "tools", "overlap.py"), os.path.join(src, "stats"), os.path.join(dst, "%s_c3_overlap.csv" % tag)], check=False)
+# period, kernel durations and the stagger of the two half-frame kernels over time, from the kernel trace of the --stats pass
 subprocess.run([sys.executable, os.path.join(root, "tools", "step_periods.py"), os.path.join(src, "stats")], check=False,
                stdout=open(os.path.join(dst, "%s_c3_step_periods.txt" % tag), "w"))
