@@ -434,7 +434,7 @@ struct rt_tracer {
       if (build_lists && !lists_inline) build_tile_lists_ahead(p);
       // The two halves overlap best in ANTI-phase (one half's drain under the other's bulk); started together -- both
       // released by the same event, or from an idle device -- they can lock IN phase and stay there for a whole run
-      // (measured at C3: 93 instead of 80 us per step, profiles/r03_b_phase_regimes.txt).  The first split launch after
+      // (measured at C3: 93 instead of 80 us per step, profiles/r03_phase_regimes.txt).  The first split launch after
       // the tracer was idle therefore lets its lower half start behind its upper half: a stagger of one half-frame kernel
       // that has the device to itself, i.e. about half a step, whatever the workload.  Later launches free-run.
       const bool stagger = stagger_next.exchange(false) && !no_stagger;
@@ -558,7 +558,7 @@ struct rt_tracer {
   // The lists live in a small ring of buffers and are built on a stream of their own (stream_l, high priority): a build is
   // enqueued when the launch that needs it is enqueued, so it runs UNDER the trace kernels of the previous launch instead of
   // in front of its own (measured in-stream: each half-frame build took 35-45 us competing for wave slots with the other
-  // half's trace kernel and stalled its own stream meanwhile, profiles/r03_a_lists_inline_timeline.txt).  Ordering: the trace
+  // half's trace kernel and stalled its own stream meanwhile, profiles/r03_lists_inline_timeline.txt).  Ordering: the trace
   // streams wait for list_ready[slot] (recorded on stream_l behind the build); a build into a slot waits for the events
   // recorded on the trace streams when that slot was retired (its last readers), kListRing - 1 builds earlier.
   // RT_MI355X_LISTS_INLINE=1: build on the trace streams, one slot (A/B).
