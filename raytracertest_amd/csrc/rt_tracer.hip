@@ -426,7 +426,7 @@ struct rt_tracer {
       if (timed) HIP_CHECK(hipEventRecord(e.a, stream));
       if (build_lists && lists_inline) HIP_CHECK(rtk::launch_tile_lists(p, fma, stream));   // part of the launch: timed with it
       if (have_lists) wait_for_lists(stream, list_waited_a);
-      attach_macro_lists(p, 0, stream);                                  // part of the launch: timed with it
+      attach_macro_lists(p, 0, stream, (flags & rtk::TRACE_ZERO_ACC) != 0u);   // part of the launch: timed with it
       HIP_CHECK(rtk::launch_trace(p, fma, filter, bin, K, stream));
       if (timed) HIP_CHECK(hipEventRecord(e.b, stream));
     } else {
@@ -446,7 +446,7 @@ struct rt_tracer {
         if (build_lists && lists_inline) HIP_CHECK(rtk::launch_tile_lists(half[h], fma, st[h]));   // each half builds the lists of its own rows
         if (have_lists) wait_for_lists(st[h], h == 0 ? list_waited_a : list_waited_b);
         if (h == 1 && stagger) HIP_CHECK(hipStreamWaitEvent(stream_b, stagger_event, 0));
-        attach_macro_lists(half[h], h, st[h]);
+        attach_macro_lists(half[h], h, st[h], (flags & rtk::TRACE_ZERO_ACC) != 0u);
         HIP_CHECK(rtk::launch_trace(half[h], fma, filter, bin, K, st[h]));
         if (h == 0 && stagger) HIP_CHECK(hipEventRecord(stagger_event, stream));
       }
@@ -677,7 +677,13 @@ struct rt_tracer {
   static constexpr uint32_t kPretestMinTris = 4096;
   static constexpr uint32_t kMacroW = 128, kMacroH = 64, kMacroCapMax = 65536;
 
-  void attach_macro_lists(rtk::TraceParams& p, int half, hipStream_t st) {
+  // Like the small scenes' tile lists the macro lists depend on camera, scene and frame only: a launch re-bins when one of
+  // them changed since the lists of this half were built (key below) -- or when it is the first launch of a Trace and the
+  // lists are not kept across Traces (bench.py's headline: every step bins afresh) -- and reads the kept lists otherwise
+  // (accumulating launches of a progressive Trace: macro_bin_kernel is 0.15 ms per half at C4, 7 % of a launch).
+  ListKey macro_key[2] = {};
+  bool macro_key_valid[2] = {false, false};
+  void attach_macro_lists(rtk::TraceParams& p, int half, hipStream_t st, bool first_launch_of_trace = true) {
     p.macro_lists = nullptr;
     if (!bin || !macro || p.n_tris <= p.bin_list) return;
     p.macro_w = kMacroW; p.macro_h = kMacroH;
@@ -695,11 +701,23 @@ struct rt_tracer {
     const size_t words = static_cast<size_t>(p.macro_nx) * ny * (p.macro_cap + 1u);
     if (words > macro_lists_words[half]) {                              // (hipFree waits for the device: safe while the other half runs)
       if (d_macro_lists[half]) (void)hipFree(d_macro_lists[half]);
-      d_macro_lists[half] = nullptr; macro_lists_words[half] = 0;
+      d_macro_lists[half] = nullptr; macro_lists_words[half] = 0; macro_key_valid[half] = false;
       HIP_CHECK(hipMalloc(&d_macro_lists[half], words * sizeof(uint32_t)));
       macro_lists_words[half] = words;
     }
     p.macro_lists = d_macro_lists[half];
+    ListKey k;
+    memset(&k, 0, sizeof k);                       // padding too: the key is compared bytewise
+    memcpy(k.cam, p.cam, sizeof k.cam);
+    k.half_height = p.half_height; k.aspect = p.aspect; k.focal = p.focal; k.aperture = p.aperture;
+    k.W = p.W; k.H = p.H; k.row0 = p.row0; k.rows = p.rows; k.bin_list = p.macro_cap * 65536u + p.macro_w * 256u + p.macro_h; k.n_tris = p.n_tris;
+    k.scene_generation = scene_generation; k.fma = fma;
+    static const bool never = [] { const char* e = getenv("RT_MI355X_NO_LIST_REUSE"); return e && e[0] == '1'; }();
+    const bool same = macro_key_valid[half] && memcmp(&k, &macro_key[half], sizeof k) == 0 && !never &&
+                      !(first_launch_of_trace && !reuse_across_traces);
+    if (same) return;
+    macro_key[half] = k;
+    macro_key_valid[half] = true;
     HIP_CHECK(rtk::launch_macro_bin(p, fma, st));
   }
 

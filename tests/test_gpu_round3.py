@@ -226,3 +226,36 @@ def test_small_scene_path_with_an_explicit_long_list(rt, orc):
     count, winner, sure = g.DebugTileLists()
     assert 0 < count.max() <= 300 and (winner[sure] < 300).all()
     g.close()
+
+
+def test_dense_scene_macro_lists_are_kept_between_launches_and_rebuilt_on_change(rt, orc):
+    """Dense scenes: the macro-tile lists are re-binned when camera, scene or frame changed (or at the first launch of a Trace
+    with list reuse off) and kept otherwise.  Accumulating split launches that reuse them, a camera rotation in between, a
+    second scene and both reuse modes all end bit-identical to the oracle."""
+    from raytracertest_amd import scenes
+    scn = scenes.random_triangles(4200, 5)
+    W, H = 96, 136
+    g = rt.RayTracer((W, H), (0, 0, 0), (0.0, 0.0), 70.0, 6.0, 0.05, seed=4)
+    o = orc.OracleTracer(W, H, (0.0, 0.0), 70.0, 6.0, 0.05, seed=4, contract=1, nthreads=8)
+    assert g.UploadScene(scn) and o.upload_scene(scn)
+
+    def same():
+        g.Sync()
+        assert np.array_equal(g.RenderBuffer().view(np.uint32), o.render.view(np.uint32)) and np.array_equal(g.RngStates(), o.rng)
+
+    g.Launch(2, clear_first=True); g.Launch(1); g.Launch(2, emit_image=True)      # bins once, reuses twice (split launches)
+    o.trace(0, 0); o.launch(2); o.launch(1); o.launch(2)
+    same()
+    g.RotateCamera((0.03, -0.05)); o.rotate_camera((0.03, -0.05))
+    g.Launch(1); g.Launch(1)                                                     # new camera: re-binned, then reused
+    o.launch(1); o.launch(1)
+    same()
+    g.SetListReuse(False)
+    g.TraceEnqueue(2, 1); o.trace(2, 1)                                          # first launch of a Trace re-bins, the second reuses
+    same()
+    scn2 = scenes.random_triangles(4300, 6)
+    assert g.UploadScene(scn2) and o.upload_scene(scn2)
+    g.Trace(2, 1, 0); assert g.Wait(); o.trace(2, 1)                             # unsplit launches of the render thread
+    same()
+    assert np.array_equal(g.Image(), o.image)
+    g.close()
