@@ -321,8 +321,8 @@ int rt_dbg_focal_boxes(rt_tracer* t, float curv_scale, float* boxes, size_t boxe
  *   two-level list builder is in use; level 3 is meaningless otherwise), lens radius A, orad[3], fc[3], followed by
  *   n_tris records.  forms == 0 (small-scene instantiation), 12 floats: flags (1 = kept, 2 = certainly hit by every ray of the
  *   family), det_lo, det_hi, U_lo, U_hi, V_lo, V_hi (bounds of det', U', V' = the reference's det, U = dot(tv, pv), V = dot(dir, qv)
- *   of Kernels.cuh:40,50,57 times |F - o|), q_lo, q_hi (bounds of t / |F - o|, t of Kernels.cuh:63), Nt_lo, Nt_hi, 0.
- *   forms != 0 (large-scene instantiation with the per-sample forms), 32 floats: flags (1 = kept), the six ends, 5 x 0, then the
+ *   of Kernels.cuh:40,50,57 times |F - o|), q_lo, q_hi (bounds of t / |F - o|, t of Kernels.cuh:63), S_lo, S_hi (bounds of det' - U' - V'), 0.
+ *   forms != 0 (large-scene instantiation with the per-sample forms), 32 floats: flags (1 = kept), the six ends, S_lo, S_hi, 3 x 0, then the
  *   forms {F1.c0, cx, cy, F2..., F3..., g1.xyz, g2.xyz, g3.xyz} each form scaled by its power of two, the gradients the fp16 values the kernel stores, 2 x 0. */
 int rt_dbg_classify(rt_tracer* t, uint32_t level, uint32_t forms, uint32_t slack_milli, const uint32_t* regions, uint32_t n_regions,
                     float* out, size_t capacity_floats);

@@ -330,8 +330,8 @@ void orc_radiance(const orc_scene* sc, const float ray[6], int contract, float r
 void orc_probe_init(orc_probe_tri* out, uint32_t n_tris) {
   for (uint32_t i = 0; i < n_tris; ++i) {
     memset(out + i, 0, sizeof out[i]);
-    out[i].det_min = out[i].U_min = out[i].V_min = out[i].q_min = INFINITY;
-    out[i].det_max = out[i].U_max = out[i].V_max = out[i].q_max = -INFINITY;
+    out[i].det_min = out[i].U_min = out[i].V_min = out[i].q_min = out[i].S_min = INFINITY;
+    out[i].det_max = out[i].U_max = out[i].V_max = out[i].q_max = out[i].S_max = -INFINITY;
   }
 }
 

@@ -128,6 +128,7 @@ typedef struct orc_probe_tri {
   uint32_t nan_rays, form_rejects, form_wrong, pad;   /* rays whose det, U or V is NaN; rays the per-sample forms skip; of those, hit */
   double det_min, det_max, U_min, U_max, V_min, V_max;   /* over the rays: det |w|, U |w|, V |w| (w = focal point - lens point) */
   double q_min, q_max;                      /* over the hit rays: t / |w| */
+  double S_min, S_max;                      /* over the rays: (det - U - V) |w|, det |w| times the third barycentric coordinate */
 } orc_probe_tri;
 void orc_probe_init(orc_probe_tri* out, uint32_t n_tris);
 void orc_tile_probe(const orc_scene* sc, const orc_camera* cam, uint32_t W, uint32_t H, const uint32_t* pixels,

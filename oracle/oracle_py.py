@@ -47,7 +47,8 @@ class Frame(C.Structure):
 PROBE_DTYPE = np.dtype([("rays", np.uint32), ("hits", np.uint32), ("wins", np.uint32), ("nan_hits", np.uint32),
                         ("nan_rays", np.uint32), ("form_rejects", np.uint32), ("form_wrong", np.uint32), ("pad", np.uint32),
                         ("det_min", np.float64), ("det_max", np.float64), ("U_min", np.float64), ("U_max", np.float64),
-                        ("V_min", np.float64), ("V_max", np.float64), ("q_min", np.float64), ("q_max", np.float64)])
+                        ("V_min", np.float64), ("V_max", np.float64), ("q_min", np.float64), ("q_max", np.float64),
+                        ("S_min", np.float64), ("S_max", np.float64)])
 
 _lib = None
 

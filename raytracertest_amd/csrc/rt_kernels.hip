@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void dbg_classify_kernel(const TraceParams p, 
     const float4 A0 = p.tri_a[2u * tri], A1 = p.tri_a[2u * tri + 1u];
     const float bz = p.tri_b[tri];
     float* const r = o + 16u + static_cast<size_t>(tri) * stride;
-    float ends[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    float ends[10] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     if constexpr (FORMS) {
       float forms[18];
 #pragma unroll
@@ -237,7 +237,8 @@ __global__ __launch_bounds__(256) void dbg_classify_kernel(const TraceParams p, 
 #pragma unroll
       for (int i = 0; i < 6; ++i) r[1 + i] = ends[i];
 #pragma unroll
-      for (int i = 7; i < 12; ++i) r[i] = 0.0f;
+      for (int i = 9; i < 12; ++i) r[i] = 0.0f;
+      r[7] = ends[8]; r[8] = ends[9];                                // S_lo, S_hi
 #pragma unroll
       for (int i = 0; i < 9; ++i) r[12 + i] = forms[i];
 #pragma unroll
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(256) void dbg_classify_kernel(const TraceParams p, 
       r[0] = (keep ? 1.0f : 0.0f) + ((fam.usable && sure) ? 2.0f : 0.0f);
 #pragma unroll
       for (int i = 0; i < 6; ++i) r[1 + i] = ends[i];
-      r[7] = q[0]; r[8] = q[1]; r[9] = ends[6]; r[10] = ends[7]; r[11] = 0.0f;
+      r[7] = q[0]; r[8] = q[1]; r[9] = ends[8]; r[10] = ends[9]; r[11] = 0.0f;   // q bounds; S_lo, S_hi
     }
   }
 }

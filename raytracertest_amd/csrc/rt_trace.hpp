@@ -273,6 +273,13 @@ __device__ __forceinline__ void test_triangle(const float4 A0, const float4 A1, 
 //     U_lo > 1.0002 * det_hi                       every unculled ray has u > 1
 //     V_hi < -1e-6 * det_hi                        every remaining ray has v < 0
 //     U_lo + V_lo > 1.0002 * det_hi                every remaining ray has u + v > 1
+//     S_hi < -2e-4 * det_hi                        the same, from S' = det' - U' - V' bounded as ONE polynomial:
+//                                                  S' = Sc + dF.(N - e2 x tvc - tvc x e1) - do.(N + G x e2 + e1 x G) - bilinear terms;
+//                                                  per ray U' + V' > det' + 2e-4 det_hi >= 1.0002 det'.  The gradients of the
+//                                                  three polynomials largely cancel in the sum (S' / det' is the third
+//                                                  barycentric coordinate), so this is the rule that drops a triangle whose
+//                                                  v1-v2 edge separates it from the family: the line above needs the footprint
+//                                                  to be small against BOTH other coordinates' ranges.
 // because the per-ray rules proven above test_triangle() are homogeneous in |w| > 0.  Any NaN
 // makes the comparisons false -> the triangle is kept and the exact tests decide.
 // tests/test_gpu_parity.py::test_binning_* and tools/stress_binning.py compare BIN against the
@@ -426,6 +433,9 @@ __device__ __forceinline__ TileFamily make_family(const TraceParams& p, const Fo
 //     U_lo >= 1e-4 det_hi (> 0)         u = fl(U * fl(1/det)) >= 0 (:51), product of two positive numbers
 //     V_lo >= 1e-4 det_hi               v >= 0 (:58)
 //     U_hi + V_hi <= 0.9999 det_lo      u + v <= 0.9999 (1 + 4 ulp) < 1, hence also u <= 1 (:51,:58)
+//       or  S_lo >= 1e-4 det_hi         the same claim from S' = det' - U' - V' bounded as one polynomial: per ray
+//                                       U' + V' <= det' - 1e-4 det_hi <= 0.9999 det'  (the tighter of the two by far: the
+//                                       separate ends ignore that U', V' and det' move together across the family)
 //     |e2|.|tv x e1| lmax < 1e37 det_lo t = dot(e2, qv) * inv (:63) is finite, so -FLT_MAX < t records the hit (:84)
 // Any NaN makes a comparison false -> not sure.
 // WHICH hit wins (farthest, Kernels.cuh:84) is decided the same way.  The reference's t = dot(e2, (o - v0) x e1) / det
@@ -439,8 +449,14 @@ __device__ __forceinline__ TileFamily make_family(const TraceParams& p, const Fo
 // colour.  Its samples keep their RNG draws and their additions, nothing else.  (Not with spheres, smooth normals or
 // the nearest-hit rule, which need t, u, v.)
 // dbg (harness only, null in every product call): the interval ends the verdicts are taken from --
-// {det_lo, det_hi, U_lo, U_hi, V_lo, V_hi, Nt_lo, Nt_hi} (Nt only with SURE).
-template <bool FORMS = false, bool SURE = false, class SL = SlackProduct>
+// {det_lo, det_hi, U_lo, U_hi, V_lo, V_hi, Nt_lo, Nt_hi, S_lo, S_hi} (Nt only with SURE; S' = det' - U' - V').
+#ifndef RT_TRACE_THIRD_BLOCK
+#define RT_TRACE_THIRD_BLOCK true
+#endif
+#ifndef RT_TRACE_THIRD_WAVE
+#define RT_TRACE_THIRD_WAVE (!PRE)
+#endif
+template <bool FORMS = false, bool SURE = false, class SL = SlackProduct, bool THIRD = !FORMS>
 __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0, V3 e1, V3 e2, float* forms = nullptr,
                                                      bool* sure_hit = nullptr, float* q = nullptr, float* dbg = nullptr) {
   // rounding allowance relative to the magnitude sums (DESIGN.md 4.1 "Rounding budget": <= ~20 half-ulps are
@@ -463,6 +479,7 @@ __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0,
     G[i] = f.fc[i] - v0v[i];
   }
   float detc = 0.0f, det_rad = 0.0f, Uc = 0.0f, U_rad = 0.0f, Vc = 0.0f, V_rad = 0.0f;
+  float S_rad = 0.0f, cs[3];                                        // S' = det' - U' - V' bounded as ONE polynomial (see below)
   float DR = 0.0f, UR = 0.0f, VR = 0.0f;                            // FORMS: radii for a known origin
   float tmag = 0.0f;                                                // SURE: >= |dot(e2, (o - v0) x e1)|
   float Ntc = 0.0f, Nt_rad = 0.0f;                                  // SURE: Nt = -(o - v0).N at the lens centre, radius over the lens
@@ -492,6 +509,16 @@ __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0,
     Vc += wc[i] * txe1;
     V_rad += a[i] * __builtin_fabsf(e1xG) + r[i] * (__builtin_fabsf(txe1) + axe1) + c * (W[i] * Txe1 + a[i] * Gabs);
     cn[i] = __builtin_fabsf(N_i); cu[i] = __builtin_fabsf(Gxe2) + rxe2; cv[i] = __builtin_fabsf(e1xG);
+    // S' = det' - U' - V' (det' times the third barycentric coordinate) = Sc + dF.(N - e2 x tvc - tvc x e1) - do.(N + G x e2 + e1 x G)
+    // - the two bilinear terms: the three gradients largely cancel (for a ray family inside the triangle's plane footprint
+    // |N - ...| is the gradient of ONE edge function), which the sum of the separate interval ends cannot see.
+    if constexpr (THIRD) {
+      cs[i] = __builtin_fabsf((N_i + Gxe2) + e1xG);
+      S_rad += (r[i] * __builtin_fabsf((N_i - e2xt) - txe1) + a[i] * cs[i]) + (a[i] * rxe2 + r[i] * axe1) +
+               c * ((W[i] * Nabs + T[i] * Wxe2) + (W[i] * Txe1 + 2.0f * (a[i] * Gabs)));
+    } else {
+      cs[i] = 0.0f;
+    }
     if constexpr (SURE) {
       tmag += E2[i] * Txe1;
       Ntc -= tvc[i] * N_i;
@@ -566,19 +593,25 @@ __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0,
   U_rad -= disk * fminf(cu[0], cu[1]);
   V_rad -= disk * fminf(cv[0], cv[1]);
   if constexpr (SURE) Nt_rad -= dn;
+  S_rad -= disk * fminf(cs[0], cs[1]);
   det_rad = det_rad * RT_SLKM(1e-5f);
   U_rad = U_rad * RT_SLKM(1e-5f);
   V_rad = V_rad * RT_SLKM(1e-5f);
+  S_rad = S_rad * RT_SLKM(1e-5f);
   const float det_hi = detc + det_rad;
   const float U_lo = Uc - U_rad, U_hi = Uc + U_rad, V_lo = Vc - V_rad, V_hi = Vc + V_rad;
+  const float Sc = (detc - Uc) - Vc;
+  // (THIRD = false -- the wave-level call of the dense-scene kernels, whose per-sample form F3 is this rule per ray and whose
+  // 128-VGPR budget the extra sums overflow: 24 -> 92 bytes of scratch per lane -- leaves the S rules out: -inf / +inf)
+  const float S_lo = THIRD ? Sc - S_rad : -__builtin_inff(), S_hi = THIRD ? Sc + S_rad : __builtin_inff();   // bounds of the reference's det' - U' - V' per ray
   const float neg = det_hi * -1e-6f, big = det_hi * 1.0002f;
   if (dbg != nullptr) {
-    dbg[0] = detc - det_rad; dbg[1] = det_hi; dbg[2] = U_lo; dbg[3] = U_hi; dbg[4] = V_lo; dbg[5] = V_hi;
+    dbg[0] = detc - det_rad; dbg[1] = det_hi; dbg[2] = U_lo; dbg[3] = U_hi; dbg[4] = V_lo; dbg[5] = V_hi; dbg[8] = S_lo; dbg[9] = S_hi;
   }
   if constexpr (SURE) {
     const float det_lo = detc - det_rad;
     *sure_hit = (det_lo > (RT_EPS * 1.0001f) * f.lmax) && (U_lo >= 1e-4f * det_hi) && (V_lo >= 1e-4f * det_hi) &&
-                ((U_hi + V_hi) <= 0.9999f * det_lo) && (tmag * f.lmax < 1e37f * det_lo);
+                (((U_hi + V_hi) <= 0.9999f * det_lo) || (S_lo >= 1e-4f * det_hi)) && (tmag * f.lmax < 1e37f * det_lo);
     const float nt_rad = (Nt_rad + c * tmag) * RT_SLKM(1e-5f);
     const float nt_lo = Ntc - nt_rad, nt_hi = Ntc + nt_rad;
     if (dbg != nullptr) { dbg[6] = nt_lo; dbg[7] = nt_hi; }
@@ -588,7 +621,7 @@ __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0,
   }
   const bool all_culled = det_hi < RT_EPS * f.lmin;
   const bool pos = det_hi > 0.0f;
-  const bool out = pos && ((U_hi < neg) || (U_lo > big) || (V_hi < neg) || ((U_lo + V_lo) > big));
+  const bool out = pos && ((U_hi < neg) || (U_lo > big) || (V_hi < neg) || ((U_lo + V_lo) > big) || (S_hi < det_hi * -2e-4f));
   return all_culled || out;
 }
 
@@ -1116,6 +1149,11 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   // block- and wave-level classification are what made the 128-VGPR kernel spill (32 bytes of scratch per lane): their state
   // is requested behind the classification instead (one exposed load latency per wave, hidden by the other three waves).
   constexpr bool RNG_LATE = PRE && BIN && !ONEPASS;
+  // The third-edge rules of tile_misses_triangle inside this kernel (block and wave level of dense scenes; the macro level and the
+  // small scenes' list builders always have them): at the block level always, at the wave level not in the instantiations with
+  // the per-sample forms, whose F3 is the same rule per ray and whose 128-VGPR budget the extra sums overflow (K = 4: 24 -> 92
+  // bytes of scratch per lane).  C4, interleaved on one device: macro level only 3.97 ms, + block level 3.75 ms, + wave level 4.55 ms.
+  constexpr bool THIRD_BLOCK = RT_TRACE_THIRD_BLOCK, THIRD_WAVE = RT_TRACE_THIRD_WAVE;
   if constexpr (!RNG_LATE) load_rng();
 
 
@@ -1230,7 +1268,7 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
           const float bz = p.tri_b[ti];
           bool keep = valid;
           if (bfam.usable)
-            keep = valid && !tile_misses_triangle(bfam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z});
+            keep = valid && !tile_misses_triangle<false, false, SlackProduct, THIRD_BLOCK>(bfam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z});
           const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
           uint32_t* const slot = bcnt + (step & 1u) * 4u;          // double-buffered: one barrier per step
           if (lane == 0u) slot[wave] = static_cast<uint32_t>(__builtin_popcountll(m));
@@ -1270,9 +1308,9 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
       if (fam.usable) {
         if constexpr (PRETEST && WF) {
           if (pretest) keep = valid && !tile_misses_triangle<true>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z}, forms);
-          else keep = valid && !tile_misses_triangle(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z});
+          else keep = valid && !tile_misses_triangle<false, false, SlackProduct, THIRD_WAVE>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z});
         } else {
-          keep = valid && !tile_misses_triangle(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z});
+          keep = valid && !tile_misses_triangle<false, false, SlackProduct, THIRD_WAVE>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z});
         }
       }
       const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);

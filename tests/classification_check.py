@@ -98,7 +98,7 @@ class Tally:
         self.form_wrong = 0
         self.form_rejects = self.form_tests = 0
         self.needed = 0.0               # max needed scale of the allowances: det', U', V'
-        self.needed_by = {"det": 0.0, "U": 0.0, "V": 0.0}
+        self.needed_by = {"det": 0.0, "U": 0.0, "V": 0.0, "S": 0.0}
         self.needed_q = 0.0             # how much of the 1e-4 margin of the winner rule the q bounds use
         self.nan_pairs = 0
         self.examples = []
@@ -215,7 +215,10 @@ def check_region(tag, probe, nohit, rays, recs, hdrs, forms=False, tile_word=Non
     if usable:
         r0 = recs[0].astype(np.float64) if 0 in recs else None
         fin = np.isfinite(r1[:, 1:7]).all(axis=1) & (probe["nan_rays"] == 0)
-        for name, lo, hi, vmin, vmax in (("det", 1, 2, "det_min", "det_max"), ("U", 3, 4, "U_min", "U_max"), ("V", 5, 6, "V_min", "V_max")):
+        s_lo = 7 if forms else 9                              # S' = det' - U' - V' as one polynomial (the third-edge rules)
+        fin = fin & np.isfinite(r1[:, s_lo:s_lo + 2]).all(axis=1)
+        for name, lo, hi, vmin, vmax in (("det", 1, 2, "det_min", "det_max"), ("U", 3, 4, "U_min", "U_max"), ("V", 5, 6, "V_min", "V_max"),
+                                         ("S", s_lo, s_lo + 1, "S_min", "S_max")):
             bad = fin & ((probe[vmin] < r1[:, lo]) | (probe[vmax] > r1[:, hi]))
             t.contain_bad += int(bad.sum())
             if bad.any() and len(t.examples) < 12:
@@ -223,7 +226,7 @@ def check_region(tag, probe, nohit, rays, recs, hdrs, forms=False, tile_word=Non
                 t.examples.append("%s: %s of triangle %d: reference [%.9g, %.9g] vs interval [%.9g, %.9g]" % (
                     tag, name, i, probe[vmin][i], probe[vmax][i], r1[i, lo], r1[i, hi]))
             if r0 is not None:
-                f0 = fin & np.isfinite(r0[:, 1:7]).all(axis=1)
+                f0 = fin & np.isfinite(r0[:, 1:7]).all(axis=1) & np.isfinite(r0[:, s_lo:s_lo + 2]).all(axis=1)
                 nd = _needed(probe[vmin], probe[vmax], r1[:, lo], r1[:, hi], r0[:, lo], r0[:, hi])
                 nd = np.where(f0, nd, 0.0)
                 t.needed_by[name] = float(nd.max(initial=0.0))
