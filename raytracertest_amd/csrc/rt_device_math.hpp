@@ -128,6 +128,22 @@ __device__ __forceinline__ uint32_t rng_next(Rng& s) {
   return s.v4 + s.d;
 }
 
+// `draws` calls of rng_next whose values nobody needs (the samples of a tile with a certain winner): five draws are one full
+// rotation of the five xorshift words, so the loop body updates them in place -- no register moves -- and the Weyl counter
+// advances once.
+__device__ __forceinline__ void rng_discard(Rng& s, uint32_t draws) {
+  auto f = [](uint32_t x, uint32_t v) -> uint32_t { const uint32_t t = x ^ (x >> 2); return (v ^ (v << 4)) ^ (t ^ (t << 1)); };
+  uint32_t i = 0;
+  for (; i + 5u <= draws; i += 5u) {
+    s.v0 = f(s.v0, s.v4); s.v1 = f(s.v1, s.v0); s.v2 = f(s.v2, s.v1); s.v3 = f(s.v3, s.v2); s.v4 = f(s.v4, s.v3);
+  }
+  for (; i < draws; ++i) {
+    const uint32_t nv = f(s.v0, s.v4);
+    s.v0 = s.v1; s.v1 = s.v2; s.v2 = s.v3; s.v3 = s.v4; s.v4 = nv;
+  }
+  s.d += 362437u * draws;
+}
+
 // curand_uniform: x * 2^-32 + 2^-33, (0, 1]
 __device__ __forceinline__ float rng_uniform(Rng& s) {
   // x * 2^-32 is exact, so the single fma rounds exactly like the reference's mul + add

@@ -48,6 +48,10 @@ struct TraceParams {
   uint32_t  macro_cap, macro_w, macro_h, macro_nx;
   uint32_t* tile_lists; // small scenes: per wave tile count | winner << 10 | certain << 31, then bin_list triangle indices
                         // (written by tile_lists_kernel, read by the trace kernel); null: no lists (large scene, no triangles)
+  // small scenes: the order in which this (half-)launch visits its trace blocks -- entry i = bx | by << 16 of the block that
+  // workgroup i (row-major over the grid) works on; null = the grid's own order.  Written by block_order_kernel from the
+  // tiles' header words: blocks with tiles that have to generate rays first, blocks of certain-winner tiles last.
+  const uint32_t* block_order;
   uint32_t  flags;     // TRACE_*
 };
 

@@ -1111,15 +1111,22 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   extern __shared__ float4 s_mem[];
 
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const uint32_t px = blockIdx.x * 32u + wave * 8u + (lane & 7u);
-  const uint32_t ly = blockIdx.y * 8u + (lane >> 3);
+  uint32_t bx = blockIdx.x, by = blockIdx.y;                       // the block of 32 x 8 pixels this workgroup traces
+  if constexpr (BIN && ONEPASS) {
+    if (p.block_order != nullptr) {                                // (scalar load: uniform address)
+      const uint32_t b = p.block_order[blockIdx.y * gridDim.x + blockIdx.x];
+      bx = b & 0xFFFFu; by = b >> 16;
+    }
+  }
+  const uint32_t px = bx * 32u + wave * 8u + (lane & 7u);
+  const uint32_t ly = by * 8u + (lane >> 3);
   const bool inside = px < p.W && ly < p.rows;
   const uint32_t cxp = inside ? px : 0u, cyp = inside ? ly : 0u;   // out-of-image lanes shadow pixel 0
   const size_t pix = static_cast<size_t>(cxp) + static_cast<size_t>(cyp) * p.W;   // Kernels.cuh:128
 
 #ifdef RT_TIMELINE
   // experiment builds only: per-wave timestamps (shader clock) + where the wave ran
-  const size_t tl_slot = ((static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 4u + wave) * 16u;
+  const size_t tl_slot = ((static_cast<size_t>(by) * gridDim.x + bx) * 4u + wave) * 16u;
   auto tl_mark = [&](uint32_t i) {
     __builtin_amdgcn_sched_barrier(0);
     if (p.timeline != nullptr && lane == 0u) p.timeline[tl_slot + i] = __builtin_amdgcn_s_memrealtime();
@@ -1166,7 +1173,7 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   uint32_t list_word = 0u;                                          // count | winner << 10 | certain << 31
   if constexpr (BIN && ONEPASS) {
     if (p.tile_lists != nullptr) {
-      const size_t slot0 = (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 4u + wave;
+      const size_t slot0 = (static_cast<size_t>(by) * gridDim.x + bx) * 4u + wave;
       // wave-uniform by construction; readfirstlane tells the compiler (scalar loop control below)
       list_word = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(p.tile_lists[slot0 * (1u + p.bin_list)])));
       loaded_sure = sure_ok && (list_word >> 31) != 0u;
@@ -1349,7 +1356,7 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   // tile's ray family only, not of the samples -- comes from tile_lists_kernel: the wave gathers the records of the listed
   // triangles into its LDS slot; a tile with a certain winner needs no records at all.
   if constexpr (BIN && ONEPASS) {
-    const size_t slot = (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 4u + wave;
+    const size_t slot = (static_cast<size_t>(by) * gridDim.x + bx) * 4u + wave;
     const uint32_t count = list_word & 0x3FFu;                         // bit 31: the tile has a certain winner, bits 10..19: its triangle
     sure_hit_tile = loaded_sure;
     sure_winner = (list_word >> 10) & 0x3FFu;
@@ -1395,25 +1402,21 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   uint32_t cnt_first = 0u;
   for (uint32_t it = 0; it < iters; ++it) {                        // FUSE: the host loop's iterations, :246
   if constexpr (FUSE) { ax = 0.0f; ay = 0.0f; az = 0.0f; }          // accu, :133
-  for (uint32_t s0 = 0; s0 < p.samples; s0 += K) {                 // :134, K samples per pass
+  uint32_t traced_samples = p.samples;
+  if constexpr (BIN && ONEPASS) {
+    // The tile's winner is hit by every ray of its family: every sample's radiance is that triangle's colour
+    // (Kernels.cuh:95-99), whatever the lens sample -- no ray, no test.  What the samples still do to the state is kept
+    // exactly: the three draws of each lens sample (Random.cuh:15-16) and the additions of :137 in sample order.
+    if (sure_hit_tile) {                                           // wave-uniform
+      rtd::rng_discard(rng, 3u * p.samples);
+      for (uint32_t s = 0; s < p.samples; ++s) { ax += sure_col.x; ay += sure_col.y; az += sure_col.z; }
+      if constexpr (STATS) st_pre += (p.samples + static_cast<uint32_t>(K) - 1u) / static_cast<uint32_t>(K);
+      traced_samples = 0u;
+    }
+  }
+  for (uint32_t s0 = 0; s0 < traced_samples; s0 += K) {            // :134, K samples per pass
     if (s0 == static_cast<uint32_t>(K)) tl_mark(2);                // first batch done (includes the wait for the RNG state)
     const uint32_t valid_k = (p.samples - s0 < static_cast<uint32_t>(K)) ? p.samples - s0 : static_cast<uint32_t>(K);
-    if constexpr (BIN && ONEPASS) {
-      // The tile's one candidate is hit by every ray of its family: every sample's radiance is that triangle's colour
-      // (Kernels.cuh:95-99), whatever the lens sample -- no ray, no test.  What a sample still does to the state is kept
-      // exactly: the three draws of its lens sample (Random.cuh:15-16) and the additions of :137 in sample order.
-      if (sure_hit_tile) {                                         // wave-uniform
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-          if (static_cast<uint32_t>(k) < valid_k) {
-            (void)rtd::rng_next(rng); (void)rtd::rng_next(rng); (void)rtd::rng_next(rng);
-            ax += sure_col.x; ay += sure_col.y; az += sure_col.z;
-          }
-        }
-        if constexpr (STATS) st_pre += 1;
-        continue;
-      }
-    }
     V3 o[K], d[K];
     float best_t[K];
     int best_i[K];

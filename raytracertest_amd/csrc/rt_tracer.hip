@@ -631,7 +631,10 @@ struct rt_tracer {
     if (!have) return;
     const size_t slot_base = static_cast<size_t>((W + 31u) / 32u) * ((p.row0 - row0) / 8u) * 4u;
     p.tile_lists = tile_lists_now() + slot_base * (1u + p.bin_list);
+    if (d_block_order_dbg != nullptr)      // [the whole band's order | the halves' orders]
+      p.block_order = d_block_order_dbg + (p.rows == rows ? 0u : static_cast<size_t>((W + 31u) / 32u) * ((rows + 7u) / 8u + 1u) + slot_base / 4u);
   }
+  uint32_t* d_block_order_dbg = nullptr;   // experiment: a block order uploaded by rt_dbg_set_block_order
 
   // The lists of the whole band, built on stream_l into the next slot of the ring (see the fields' comment).
   void build_tile_lists_ahead(const rtk::TraceParams& p_band) {
@@ -1735,6 +1738,23 @@ int rt_dbg_read_tile_lists(rt_tracer* t, uint32_t* dst, size_t capacity_words, u
     const size_t n = t->tile_lists_words < capacity_words ? t->tile_lists_words : capacity_words;
     HIP_CHECK(hipMemcpy(dst, t->tile_lists_now(), n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (words_per_tile) *words_per_tile = 1u + t->list_key.bin_list;
+  });
+}
+
+int rt_dbg_set_block_order(rt_tracer* t, const uint32_t* order, uint32_t n) {
+  if (!t || t->mg) return RT_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(t->api_mu);
+  return guarded(t, [&] {
+    t->cancel_and_join();
+    t->use_device();
+    HIP_CHECK(hipStreamSynchronize(t->main_stream()));
+    t->sync_list_stream();
+    if (t->d_block_order_dbg) { HIP_CHECK(hipFree(t->d_block_order_dbg)); t->d_block_order_dbg = nullptr; }
+    if (order == nullptr || n == 0u) return;
+    const uint32_t nb = ((t->W + 31u) / 32u) * ((t->rows + 7u) / 8u + 1u);
+    if (n != 2u * nb) throw HipFail{"block order: expected 2 x gx x (gy + 1) entries (band order, then the halves')"};
+    HIP_CHECK(hipMalloc(&t->d_block_order_dbg, static_cast<size_t>(n) * sizeof(uint32_t)));
+    HIP_CHECK(hipMemcpy(t->d_block_order_dbg, order, static_cast<size_t>(n) * sizeof(uint32_t), hipMemcpyHostToDevice));
   });
 }
 
