@@ -359,8 +359,11 @@ hipError_t launch_trace(const TraceParams& p, bool fma, bool filter, bool bin, i
   // render += 0, RNG written back, Kernels.cuh:133-146): the fused clear / BGRA8 emit / list store of the
   // launch still have to happen
   if (p.rows == 0 || p.W == 0) return hipSuccess;
-  const dim3 grid(cdiv(p.W, 32), cdiv(p.rows, 8));
-  const size_t lds = trace_lds_bytes(p, bin);
+  const bool ordered = p.block_order != nullptr && p.iters <= 1u && p.stats == nullptr;
+  if (p.block_order != nullptr && !ordered) return hipErrorInvalidValue;
+  if (ordered && p.block_count == 0u) return hipSuccess;
+  const dim3 grid = ordered ? dim3(p.block_count, 1) : dim3(cdiv(p.W, 32), cdiv(p.rows, 8));
+  const size_t lds = trace_lds_bytes(p, bin) + p.lds_pad;
   if (p.iters > 1u) {                // fused iterations: default (filtered, classified, un-instrumented) kernels only
     if (!trace_can_fuse(filter, bin) || p.stats != nullptr) return hipErrorInvalidValue;
     if (fma) launch_trace_fused<true>(p, K, grid, lds, st);
@@ -412,6 +415,29 @@ hipError_t launch_macro_bin(const TraceParams& p, bool fma, hipStream_t st) {
   const dim3 grid(cdiv(p.W, p.macro_w), cdiv(p.rows, p.macro_h));
   if (fma) hipLaunchKernelGGL(macro_bin_kernel<true>, grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL(macro_bin_kernel<false>, grid, dim3(256), 0, st, p);
+  return hipGetLastError();
+}
+
+// What `samples` samples of a certain-winner tile add up to, per triangle: the additions of Kernels.cuh:137 in sample order
+// (accu starts at 0, :133), the accumulation into a cleared RenderBuffer (:141-143) and the conversion of :164-168 -- the
+// same operations the trace kernel would run per pixel, run once per triangle.
+__global__ __launch_bounds__(256) void sure_table_kernel(const float4* __restrict__ colors, uint32_t n_tris, uint32_t samples,
+                                                          float4* __restrict__ out) {
+  const uint32_t tri = blockIdx.x * 256u + threadIdx.x;
+  if (tri >= n_tris) return;
+  const float4 col = colors[tri];
+  float ax = 0.0f, ay = 0.0f, az = 0.0f;
+  for (uint32_t s = 0; s < samples; ++s) { ax += col.x; ay += col.y; az += col.z; }
+  float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  acc.x += ax; acc.y += ay; acc.z += az;
+  const float c = static_cast<float>(samples);
+  const uint32_t bgra = rtd::pack_color(255.0f * (acc.x / c), 255.0f * (acc.y / c), 255.0f * (acc.z / c));
+  out[tri] = make_float4(ax, ay, az, __builtin_bit_cast(float, bgra));
+}
+
+hipError_t launch_sure_table(const float4* colors, uint32_t n_tris, uint32_t samples, float4* out, hipStream_t st) {
+  if (n_tris == 0u) return hipSuccess;
+  hipLaunchKernelGGL(sure_table_kernel, dim3(cdiv(n_tris, 256)), dim3(256), 0, st, colors, n_tris, samples, out);
   return hipGetLastError();
 }
 

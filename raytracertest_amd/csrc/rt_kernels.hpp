@@ -49,9 +49,14 @@ struct TraceParams {
   uint32_t* tile_lists; // small scenes: per wave tile count | winner << 10 | certain << 31, then bin_list triangle indices
                         // (written by tile_lists_kernel, read by the trace kernel); null: no lists (large scene, no triangles)
   // small scenes: the order in which this (half-)launch visits its trace blocks -- entry i = bx | by << 16 of the block that
-  // workgroup i (row-major over the grid) works on; null = the grid's own order.  Written by block_order_kernel from the
-  // tiles' header words: blocks with tiles that have to generate rays first, blocks of certain-winner tiles last.
+  // workgroup i (row-major over the grid) works on; null = the grid's own order (the product; rt_dbg_set_block_order is an
+  // experiment hook).
   const uint32_t* block_order;
+  uint32_t  block_count;    // with block_order: entries of this launch (its grid is 1-D: ceil(block_count) workgroups)
+  uint32_t  lds_pad;        // experiment: bytes of dynamic LDS added to the launch (caps the blocks per CU)
+  // small scenes: per triangle, what a pixel of a certain-winner tile accumulates in one launch of p.samples samples --
+  // {sum.x, sum.y, sum.z, bits of the BGRA8 word of a freshly cleared pixel} (sure_table_kernel; null: the kernel adds)
+  const float4* sure_table;
   uint32_t  flags;     // TRACE_*
 };
 
@@ -86,6 +91,8 @@ hipError_t launch_dbg_hit_triangle(bool fma, uint32_t n, const float* rays, cons
                                    int* hit, float* tuv, float* normal, float* point, hipStream_t st);
 bool trace_can_fuse(bool filter, bool bin);      // launches with TraceParams::iters > 1 are available
 hipError_t launch_macro_bin(const TraceParams& p, bool fma, hipStream_t st);
+// small scenes: the per-triangle table TraceParams::sure_table for launches of `samples` samples
+hipError_t launch_sure_table(const float4* colors, uint32_t n_tris, uint32_t samples, float4* out, hipStream_t st);
 // small scenes: the tiles' candidate lists + certain-winner verdicts of the (half-)launch `p` into p.tile_lists
 hipError_t launch_tile_lists(const TraceParams& p, bool fma, hipStream_t st);
 hipError_t launch_dbg_check_midrange(unsigned long long* out, hipStream_t st);

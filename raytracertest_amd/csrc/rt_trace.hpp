@@ -1112,10 +1112,13 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
 
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint32_t bx = blockIdx.x, by = blockIdx.y;                       // the block of 32 x 8 pixels this workgroup traces
+  uint32_t gxb = gridDim.x;                                        // blocks per block row
   if constexpr (BIN && ONEPASS) {
-    if (p.block_order != nullptr) {                                // (scalar load: uniform address)
-      const uint32_t b = p.block_order[blockIdx.y * gridDim.x + blockIdx.x];
+    if (p.block_order != nullptr) {                                // (scalar load: uniform address; 1-D grid)
+      if (blockIdx.x >= p.block_count) return;
+      const uint32_t b = p.block_order[blockIdx.x];
       bx = b & 0xFFFFu; by = b >> 16;
+      gxb = (p.W + 31u) / 32u;
     }
   }
   const uint32_t px = bx * 32u + wave * 8u + (lane & 7u);
@@ -1126,7 +1129,7 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
 
 #ifdef RT_TIMELINE
   // experiment builds only: per-wave timestamps (shader clock) + where the wave ran
-  const size_t tl_slot = ((static_cast<size_t>(by) * gridDim.x + bx) * 4u + wave) * 16u;
+  const size_t tl_slot = ((static_cast<size_t>(by) * gxb + bx) * 4u + wave) * 16u;
   auto tl_mark = [&](uint32_t i) {
     __builtin_amdgcn_sched_barrier(0);
     if (p.timeline != nullptr && lane == 0u) p.timeline[tl_slot + i] = __builtin_amdgcn_s_memrealtime();
@@ -1173,7 +1176,7 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   uint32_t list_word = 0u;                                          // count | winner << 10 | certain << 31
   if constexpr (BIN && ONEPASS) {
     if (p.tile_lists != nullptr) {
-      const size_t slot0 = (static_cast<size_t>(by) * gridDim.x + bx) * 4u + wave;
+      const size_t slot0 = (static_cast<size_t>(by) * gxb + bx) * 4u + wave;
       // wave-uniform by construction; readfirstlane tells the compiler (scalar loop control below)
       list_word = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(p.tile_lists[slot0 * (1u + p.bin_list)])));
       loaded_sure = sure_ok && (list_word >> 31) != 0u;
@@ -1356,7 +1359,7 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   // tile's ray family only, not of the samples -- comes from tile_lists_kernel: the wave gathers the records of the listed
   // triangles into its LDS slot; a tile with a certain winner needs no records at all.
   if constexpr (BIN && ONEPASS) {
-    const size_t slot = (static_cast<size_t>(by) * gridDim.x + bx) * 4u + wave;
+    const size_t slot = (static_cast<size_t>(by) * gxb + bx) * 4u + wave;
     const uint32_t count = list_word & 0x3FFu;                         // bit 31: the tile has a certain winner, bits 10..19: its triangle
     sure_hit_tile = loaded_sure;
     sure_winner = (list_word >> 10) & 0x3FFu;
@@ -1391,8 +1394,9 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   }
   if constexpr (RNG_LATE) load_rng();
   tl_mark(1);                                                      // family + classification done
-  float4 sure_col = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  if constexpr (BIN && ONEPASS) { if (sure_hit_tile) sure_col = p.tri_color[sure_winner]; }
+  float4 sure_col = make_float4(0.0f, 0.0f, 0.0f, 0.0f);           // the winner's colour -- or, with the table, its p.samples-fold sum
+  const bool sure_sums = BIN && ONEPASS && p.sure_table != nullptr;
+  if constexpr (BIN && ONEPASS) { if (sure_hit_tile) sure_col = sure_sums ? p.sure_table[sure_winner] : p.tri_color[sure_winner]; }
   if constexpr (STATS && BIN && ONEPASS) {                         // tiles with a certain winner; the others by list length: 0, 1, 2, more
     if (lane == 0u && p.stats != nullptr)
       atomicAdd(p.stats + (sure_hit_tile ? 13 : list_count == 0u ? 11 : list_count == 1u ? 12 : list_count == 2u ? 14 : 15), 1ull);
@@ -1409,7 +1413,8 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
     // exactly: the three draws of each lens sample (Random.cuh:15-16) and the additions of :137 in sample order.
     if (sure_hit_tile) {                                           // wave-uniform
       rtd::rng_discard(rng, 3u * p.samples);
-      for (uint32_t s = 0; s < p.samples; ++s) { ax += sure_col.x; ay += sure_col.y; az += sure_col.z; }
+      if (sure_sums) { ax = sure_col.x; ay = sure_col.y; az = sure_col.z; }      // (the same additions, done once per triangle)
+      else for (uint32_t s = 0; s < p.samples; ++s) { ax += sure_col.x; ay += sure_col.y; az += sure_col.z; }
       if constexpr (STATS) st_pre += (p.samples + static_cast<uint32_t>(K) - 1u) / static_cast<uint32_t>(K);
       traced_samples = 0u;
     }
@@ -1621,7 +1626,10 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
     p.render[pix_e] = acc;
     if (p.flags & TRACE_EMIT_IMAGE) {                               // fused rt::ConverterKernel, :164-168
       const float c = static_cast<float>(cnt);
-      const uint32_t bgra = rtd::pack_color(255.0f * (acc.x / c), 255.0f * (acc.y / c), 255.0f * (acc.z / c));
+      uint32_t bgra;
+      // a certain-winner tile on cleared accumulators: the table holds the word every pixel of it gets (wave-uniform branch)
+      if (!FUSE && sure_sums && sure_hit_tile && (p.flags & TRACE_ZERO_ACC)) bgra = __builtin_bit_cast(uint32_t, sure_col.w);
+      else bgra = rtd::pack_color(255.0f * (acc.x / c), 255.0f * (acc.y / c), 255.0f * (acc.z / c));
       p.image[pix_e] = bgra;
       // update hand-off: the same value straight into the caller-visible pinned host image (posted
       // PCIe writes, one 256-byte row segment per wave store) -- no device-to-host copy afterwards

@@ -405,6 +405,7 @@ struct rt_tracer {
     p.image = d_image;
     bool have_lists = false;
     const bool build_lists = prepare_tile_lists(p, (flags & rtk::TRACE_ZERO_ACC) != 0u, have_lists);
+    attach_sure_table(p, have_lists);
     last_k = K; last_chunk = p.chunk;
     last_lds = rtk::trace_lds_bytes(p, bin);
     // Event pairs bracket every `event_stride`-th launch (and every launch the caller waits for):
@@ -415,11 +416,27 @@ struct rt_tracer {
     const bool timed = sync_after == 1 || event_stride <= 1u || (launch_counter++ % event_stride) == 0u;
     // Tall frames: upper half on the primary stream, lower half on stream_b (see the fields' comment).
     // The split row is a multiple of 8, each half is a row band of its own (own tile / macro lists).
-    static const uint32_t split_pct = [] { const char* e = getenv("RT_MI355X_SPLIT_PCT"); const long v = e ? strtol(e, nullptr, 10) : 50; return static_cast<uint32_t>(v >= 10 && v <= 90 ? v : 50); }();
-    const uint32_t r0 = (split_launches && allow_split && p.rows >= 128u) ? ((p.rows * split_pct / 100u + 7u) / 8u) * 8u : 0u;
+    const bool class_split = d_block_order_dbg != nullptr && have_lists && iters == 1u;
+    const uint32_t r0 = (allow_split && !class_split) ? split_row(p.rows) : 0u;
     EventPair e{};
     if (timed) { e = take_events(); e.launches = 1; e.split = r0 != 0u; }
-    if (r0 == 0u) {
+    if (class_split && dbg_order_first != 0u && allow_split) {
+      // EXPERIMENT: two launches over the whole band, one per slice of the uploaded block order, on the two streams
+      fork_b();
+      if (build_lists && !lists_inline) build_tile_lists_ahead(p);
+      attach_tile_lists(p, have_lists);
+      rtk::TraceParams part[2] = {p, p};
+      part[0].block_count = dbg_order_first;
+      part[1].block_order = p.block_order + dbg_order_first; part[1].block_count = dbg_order_n - dbg_order_first; part[1].lds_pad = dbg_order_pad;
+      hipStream_t st[2] = {stream, stream_b};
+      if (timed) HIP_CHECK(hipEventRecord(e.a, stream));
+      for (int h = 0; h < 2; ++h) {
+        if (have_lists) wait_for_lists(st[h], h == 0 ? list_waited_a : list_waited_b);
+        HIP_CHECK(rtk::launch_trace(part[h], fma, filter, bin, K, st[h]));
+      }
+      if (timed) { e.split = true; HIP_CHECK(hipEventRecord(e.b, stream)); HIP_CHECK(hipEventRecord(e.c, stream_b)); }
+      mark_b_dirty();
+    } else if (r0 == 0u) {
       (void)main_stream();                                               // a launch on one stream orders behind both
       if (build_lists && !lists_inline) build_tile_lists_ahead(p);
       attach_tile_lists(p, have_lists);
@@ -559,14 +576,20 @@ struct rt_tracer {
   // enqueued when the launch that needs it is enqueued, so it runs UNDER the trace kernels of the previous launch instead of
   // in front of its own (measured in-stream: each half-frame build took 35-45 us competing for wave slots with the other
   // half's trace kernel and stalled its own stream meanwhile, profiles/r03_lists_inline_timeline.txt).  Ordering: the trace
-  // streams wait for list_ready[slot] (recorded on stream_l behind the build); a build into a slot waits for the events
-  // recorded on the trace streams when that slot was retired (its last readers), kListRing - 1 builds earlier.
+  // streams wait for list_ready[slot] (recorded on stream_l behind the build); a build into a slot waits until the slot's last
+  // readers are done.  An event record is a packet the next kernel of its stream queues behind (two of them per step cost
+  // 4 us of a 66 us C3 step), so the trace streams record a "free" event only every kFreeStride-th build -- it covers every
+  // kernel enqueued before it -- and the ring is long enough that a build always finds such an event that is at least
+  // kFreeStride builds old and still covers the readers of the slot it overwrites (build m: the oldest recorded at a build
+  // e >= m - kListRing + 1; then m - kListRing < e <= m - kFreeStride).
   // RT_MI355X_LISTS_INLINE=1: build on the trace streams, one slot (A/B).
-  static constexpr int kListRing = 3;
-  uint32_t* d_list_ring[kListRing] = {nullptr, nullptr, nullptr};
-  hipEvent_t list_ready[kListRing] = {nullptr, nullptr, nullptr};
-  hipEvent_t list_free_a[kListRing] = {nullptr, nullptr, nullptr}, list_free_b[kListRing] = {nullptr, nullptr, nullptr};
-  bool list_free_valid[kListRing] = {false, false, false};
+  static constexpr int kListRing = 8, kFreeEvents = 10;
+  int ring_n = 8, kFreeStride = 4;    // RT_MI355X_LIST_RING=slots:stride (A/B; stride <= slots - 2, or 1)
+  uint32_t* d_list_ring[kListRing] = {};
+  hipEvent_t list_ready[kListRing] = {};
+  hipEvent_t list_free_a[kFreeEvents] = {}, list_free_b[kFreeEvents] = {};
+  uint64_t list_free_build[kFreeEvents] = {};   // the build index each pair was recorded at (0 = never)
+  uint64_t list_alloc_build = 0;      // builds before this one wrote buffers that no longer exist
   int list_cur = 0;                   // slot of the current lists
   uint64_t list_builds = 0;           // builds so far; the trace streams remember which one they have waited for
   uint64_t list_waited_a = 0, list_waited_b = 0;
@@ -577,9 +600,13 @@ struct rt_tracer {
   bool no_stagger = false;                // RT_MI355X_NO_STAGGER=1 (A/B)
   size_t tile_lists_words = 0;
   uint32_t* tile_lists_now() const { return d_list_ring[list_cur]; }
+  uint32_t split_row(uint32_t band_rows) const {   // first row of the lower half of a split launch (a multiple of 8); 0 = not split
+    static const uint32_t split_pct = [] { const char* e = getenv("RT_MI355X_SPLIT_PCT"); const long v = e ? strtol(e, nullptr, 10) : 50; return static_cast<uint32_t>(v >= 10 && v <= 90 ? v : 50); }();
+    return (split_launches && band_rows >= 128u) ? ((band_rows * split_pct / 100u + 7u) / 8u) * 8u : 0u;
+  }
   void release_tile_lists() {         // callers have synchronised every stream
-    for (int r = 0; r < kListRing; ++r) { if (d_list_ring[r]) (void)hipFree(d_list_ring[r]); d_list_ring[r] = nullptr; list_free_valid[r] = false; }
-    tile_lists_words = 0; list_key_valid = false; list_cur = 0;
+    for (int r = 0; r < kListRing; ++r) { if (d_list_ring[r]) (void)hipFree(d_list_ring[r]); d_list_ring[r] = nullptr; }
+    tile_lists_words = 0; list_key_valid = false; list_cur = 0; list_alloc_build = list_builds;
   }
   void sync_list_stream() { if (stream_l) HIP_CHECK(hipStreamSynchronize(stream_l)); }
   ListKey list_key{};
@@ -601,7 +628,7 @@ struct rt_tracer {
       HIP_CHECK(hipStreamSynchronize(main_stream()));
       sync_list_stream();
       release_tile_lists();
-      for (int r = 0; r < (lists_inline ? 1 : kListRing); ++r) {
+      for (int r = 0; r < (lists_inline ? 1 : ring_n); ++r) {
         HIP_CHECK(hipMalloc(&d_list_ring[r], words * sizeof(uint32_t)));
         // count 0 everywhere until a launch builds; on the stream the builds run on (a hipMemset on the null stream is not
         // ordered with the non-blocking streams and may land AFTER the first build)
@@ -631,22 +658,58 @@ struct rt_tracer {
     if (!have) return;
     const size_t slot_base = static_cast<size_t>((W + 31u) / 32u) * ((p.row0 - row0) / 8u) * 4u;
     p.tile_lists = tile_lists_now() + slot_base * (1u + p.bin_list);
-    if (d_block_order_dbg != nullptr)      // [the whole band's order | the halves' orders]
-      p.block_order = d_block_order_dbg + (p.rows == rows ? 0u : static_cast<size_t>((W + 31u) / 32u) * ((rows + 7u) / 8u + 1u) + slot_base / 4u);
+    if (d_block_order_dbg != nullptr && p.rows == rows) {   // (the whole band: class-split launches do not use row halves)
+      p.block_order = d_block_order_dbg;
+      p.block_count = dbg_order_n;
+    }
   }
-  uint32_t* d_block_order_dbg = nullptr;   // experiment: a block order uploaded by rt_dbg_set_block_order
+  // Experiment hook (rt_dbg_set_block_order, tools/block_order_experiment.py): the order in which a small-scene launch visits
+  // its trace blocks.  Grouping the blocks of certain-winner tiles apart from those that generate rays measured 60.8 -> 57.5 us
+  // per C3 step before the certain-winner path had its table (2.4 % after); a device-side ordering pass behind every list
+  // build cost more than that on the list stream, so the product launches in grid order.
+  uint32_t* d_block_order_dbg = nullptr;
+  uint32_t dbg_order_n = 0, dbg_order_first = 0, dbg_order_pad = 0;   // entries; entries of the first slice (0: one launch); LDS pad of the second
+
+  // Small scenes: the per-triangle table of what a certain-winner pixel accumulates in a launch of `samples` samples
+  // (rtk::sure_table_kernel), rebuilt when the sample count or the scene changed.  Built on the stream that orders behind
+  // both trace streams: earlier launches may still read the previous table.
+  float4* d_sure_table = nullptr;
+  uint32_t sure_table_cap = 0, sure_table_samples = 0;
+  uint64_t sure_table_scene = ~0ull;
+  void attach_sure_table(rtk::TraceParams& p, bool have) {
+    p.sure_table = nullptr;
+    static const bool off = [] { const char* e = getenv("RT_MI355X_NO_SURE_TABLE"); return e && e[0] == '1'; }();
+    if (!have || off || p.n_tris == 0u) return;
+    if (sure_table_samples != p.samples || sure_table_scene != scene_generation || sure_table_cap < p.n_tris) {
+      hipStream_t st = main_stream();
+      if (sure_table_cap < p.n_tris) {
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (d_sure_table) { HIP_CHECK(hipFree(d_sure_table)); d_sure_table = nullptr; }
+        HIP_CHECK(hipMalloc(&d_sure_table, static_cast<size_t>(p.n_tris) * sizeof(float4)));
+        sure_table_cap = p.n_tris;
+      }
+      HIP_CHECK(rtk::launch_sure_table(p.tri_color, p.n_tris, p.samples, d_sure_table, st));
+      sure_table_samples = p.samples; sure_table_scene = scene_generation;
+    }
+    p.sure_table = d_sure_table;
+  }
 
   // The lists of the whole band, built on stream_l into the next slot of the ring (see the fields' comment).
   void build_tile_lists_ahead(const rtk::TraceParams& p_band) {
-    if (list_builds > 0) {                                             // retire the current slot: its last readers are what the trace streams hold now
-      HIP_CHECK(hipEventRecord(list_free_a[list_cur], stream));
-      HIP_CHECK(hipEventRecord(list_free_b[list_cur], stream_b));
-      list_free_valid[list_cur] = true;
+    const uint64_t m = list_builds;                                    // this build's index
+    if (m > 0 && m % kFreeStride == 0) {                               // everything the trace streams hold now: the readers of every earlier build
+      const int i = static_cast<int>((m / kFreeStride) % kFreeEvents);
+      HIP_CHECK(hipEventRecord(list_free_a[i], stream));
+      HIP_CHECK(hipEventRecord(list_free_b[i], stream_b));
+      list_free_build[i] = m;
     }
-    const int r = static_cast<int>(list_builds % kListRing);
-    if (list_free_valid[r]) {
-      HIP_CHECK(hipStreamWaitEvent(stream_l, list_free_a[r], 0));
-      HIP_CHECK(hipStreamWaitEvent(stream_l, list_free_b[r], 0));
+    const int r = static_cast<int>(m % ring_n);
+    if (m >= list_alloc_build + ring_n) {                              // the slot has readers: builds since the buffers exist wrap around
+      const uint64_t e = ((m - ring_n + 1 + kFreeStride - 1) / kFreeStride) * kFreeStride;   // oldest record that covers build m - ring_n
+      const int i = static_cast<int>((e / kFreeStride) % kFreeEvents);
+      if (list_free_build[i] != e) throw HipFail{"list ring: the free event of the slot's readers is missing"};
+      HIP_CHECK(hipStreamWaitEvent(stream_l, list_free_a[i], 0));
+      HIP_CHECK(hipStreamWaitEvent(stream_l, list_free_b[i], 0));
     }
     list_cur = r;
     rtk::TraceParams q = p_band;
@@ -979,6 +1042,10 @@ int rt_tracer_create_ex(const uint32_t imageSize[2], const float cameraPosition[
   { const char* np = getenv("RT_MI355X_NO_PRETEST"); t->pretest = !(np && np[0] == '1'); }
   { const char* nh = getenv("RT_MI355X_NO_SUREHIT"); t->sure_hit = (opt.flags & RT_FLAG_NO_SURE_HIT) == 0 && !(nh && nh[0] == '1'); }
   { const char* ns = getenv("RT_MI355X_NO_SPLIT"); t->split_launches = !(ns && ns[0] == '1'); }
+  if (const char* lr = getenv("RT_MI355X_LIST_RING")) {
+    int n = 0, st = 0;
+    if (sscanf(lr, "%d:%d", &n, &st) == 2 && n >= 3 && n <= rt_tracer::kListRing && st >= 1 && (st == 1 || st <= n - 2)) { t->ring_n = n; t->kFreeStride = st; }
+  }
   if (const char* es = getenv("RT_MI355X_EVENT_STRIDE")) t->event_stride = static_cast<uint32_t>(strtoul(es, nullptr, 10));
   {
     const char* nm = getenv("RT_MI355X_NO_MACRO");
@@ -1021,8 +1088,8 @@ int rt_tracer_create_ex(const uint32_t imageSize[2], const float cameraPosition[
       }
       HIP_CHECK(hipEventCreateWithFlags(&t->stagger_event, hipEventDisableTiming));
       { const char* ns2 = getenv("RT_MI355X_NO_STAGGER"); t->no_stagger = ns2 && ns2[0] == '1'; }
-      for (int r = 0; r < rt_tracer::kListRing; ++r) {
-        HIP_CHECK(hipEventCreateWithFlags(&t->list_ready[r], hipEventDisableTiming));
+      for (int r = 0; r < rt_tracer::kListRing; ++r) HIP_CHECK(hipEventCreateWithFlags(&t->list_ready[r], hipEventDisableTiming));
+      for (int r = 0; r < rt_tracer::kFreeEvents; ++r) {
         HIP_CHECK(hipEventCreateWithFlags(&t->list_free_a[r], hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&t->list_free_b[r], hipEventDisableTiming));
       }
@@ -1074,8 +1141,9 @@ void rt_tracer_destroy(rt_tracer* t) {                                   // RayT
   for (EventPair& e : t->free_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); (void)hipEventDestroy(e.c); }
   if (t->stream_l) (void)hipStreamSynchronize(t->stream_l);
   t->release_tile_lists();
-  for (int r = 0; r < rt_tracer::kListRing; ++r) {
+  for (int r = 0; r < rt_tracer::kListRing; ++r)
     if (t->list_ready[r]) (void)hipEventDestroy(t->list_ready[r]);
+  for (int r = 0; r < rt_tracer::kFreeEvents; ++r) {
     if (t->list_free_a[r]) (void)hipEventDestroy(t->list_free_a[r]);
     if (t->list_free_b[r]) (void)hipEventDestroy(t->list_free_b[r]);
   }
@@ -1086,6 +1154,8 @@ void rt_tracer_destroy(rt_tracer* t) {                                   // RayT
   if (t->d_tri) (void)hipFree(t->d_tri);
   if (t->d_tri_b) (void)hipFree(t->d_tri_b);
   if (t->d_tri_color) (void)hipFree(t->d_tri_color);
+  if (t->d_sure_table) (void)hipFree(t->d_sure_table);
+  if (t->d_block_order_dbg) (void)hipFree(t->d_block_order_dbg);
   if (t->d_spheres) (void)hipFree(t->d_spheres);
   t->release_buffers();
   if (t->handoff_event) (void)hipEventDestroy(t->handoff_event);
@@ -1741,7 +1811,7 @@ int rt_dbg_read_tile_lists(rt_tracer* t, uint32_t* dst, size_t capacity_words, u
   });
 }
 
-int rt_dbg_set_block_order(rt_tracer* t, const uint32_t* order, uint32_t n) {
+int rt_dbg_set_block_order(rt_tracer* t, const uint32_t* order, uint32_t n, uint32_t n_first, uint32_t lds_pad_second) {
   if (!t || t->mg) return RT_ERR_INVALID;
   std::lock_guard<std::mutex> lk(t->api_mu);
   return guarded(t, [&] {
@@ -1751,10 +1821,11 @@ int rt_dbg_set_block_order(rt_tracer* t, const uint32_t* order, uint32_t n) {
     t->sync_list_stream();
     if (t->d_block_order_dbg) { HIP_CHECK(hipFree(t->d_block_order_dbg)); t->d_block_order_dbg = nullptr; }
     if (order == nullptr || n == 0u) return;
-    const uint32_t nb = ((t->W + 31u) / 32u) * ((t->rows + 7u) / 8u + 1u);
-    if (n != 2u * nb) throw HipFail{"block order: expected 2 x gx x (gy + 1) entries (band order, then the halves')"};
+    const uint32_t nb = ((t->W + 31u) / 32u) * ((t->rows + 7u) / 8u);
+    if (n != nb || n_first > n) throw HipFail{"block order: expected one entry per trace block of the band"};
     HIP_CHECK(hipMalloc(&t->d_block_order_dbg, static_cast<size_t>(n) * sizeof(uint32_t)));
     HIP_CHECK(hipMemcpy(t->d_block_order_dbg, order, static_cast<size_t>(n) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    t->dbg_order_n = n; t->dbg_order_first = n_first; t->dbg_order_pad = lds_pad_second;
   });
 }
 
