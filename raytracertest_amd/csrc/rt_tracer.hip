@@ -343,9 +343,12 @@ struct rt_tracer {
     if (p.chunk > 4096u) p.chunk = 4096u;                                // 144 KiB of the CU's 160 KiB LDS
     // per-wave candidate list: whole (small) scene if it fits, else 256 records = 40 KiB per
     // block -> 4 blocks per CU; 64 records = 10 KiB per block lets 8 blocks (32 waves) share a CU
-    uint32_t want = bin_list_req ? bin_list_req : ((n_tris + 63u) / 64u) * 64u;
-    want = ((want + 63u) / 64u) * 64u;
-    p.bin_list = want < 64u ? 64u : want > (bin_list_req ? 960u : 256u) ? (bin_list_req ? 960u : 256u) : want;
+    // (a trace block holds its LDS until its slowest wave is done -- in a frame of mostly certain-winner tiles most resident
+    // blocks are down to one or two live waves, and at 10 KiB per block the CU's LDS, not its wave slots, capped the waves in
+    // flight: 32-record granularity, 5 KiB per block for scenes of up to 32 triangles)
+    uint32_t want = bin_list_req ? bin_list_req : ((n_tris + 31u) / 32u) * 32u;
+    want = ((want + 31u) / 32u) * 32u;
+    p.bin_list = want < 32u ? 32u : want > (bin_list_req ? 960u : 256u) ? (bin_list_req ? 960u : 256u) : want;
     // scenes that do not fit the per-wave list: 192 records per wave + a 1024-entry block-level
     // pre-cull list keep the block at 34.9 KiB of LDS (4 blocks per CU)
     const char* nb = getenv("RT_MI355X_NO_BLOCK_LIST");
