@@ -215,10 +215,11 @@ def check_region(tag, probe, nohit, rays, recs, hdrs, forms=False, tile_word=Non
     if usable:
         r0 = recs[0].astype(np.float64) if 0 in recs else None
         fin = np.isfinite(r1[:, 1:7]).all(axis=1) & (probe["nan_rays"] == 0)
-        s_lo = 7 if forms else 9                              # S' = det' - U' - V' as one polynomial (the third-edge rules)
-        fin = fin & np.isfinite(r1[:, s_lo:s_lo + 2]).all(axis=1)
+        s_lo = 7 if forms else 9                              # S' = det' - U' - V' as one polynomial (the third-edge rules);
+        fin_all = fin                                         # -inf / +inf where the instantiation leaves the S rules out
         for name, lo, hi, vmin, vmax in (("det", 1, 2, "det_min", "det_max"), ("U", 3, 4, "U_min", "U_max"), ("V", 5, 6, "V_min", "V_max"),
                                          ("S", s_lo, s_lo + 1, "S_min", "S_max")):
+            fin = fin_all & np.isfinite(r1[:, lo]) & np.isfinite(r1[:, hi])
             bad = fin & ((probe[vmin] < r1[:, lo]) | (probe[vmax] > r1[:, hi]))
             t.contain_bad += int(bad.sum())
             if bad.any() and len(t.examples) < 12:
@@ -226,7 +227,7 @@ def check_region(tag, probe, nohit, rays, recs, hdrs, forms=False, tile_word=Non
                 t.examples.append("%s: %s of triangle %d: reference [%.9g, %.9g] vs interval [%.9g, %.9g]" % (
                     tag, name, i, probe[vmin][i], probe[vmax][i], r1[i, lo], r1[i, hi]))
             if r0 is not None:
-                f0 = fin & np.isfinite(r0[:, 1:7]).all(axis=1) & np.isfinite(r0[:, s_lo:s_lo + 2]).all(axis=1)
+                f0 = fin & np.isfinite(r0[:, 1:7]).all(axis=1) & np.isfinite(r0[:, lo]) & np.isfinite(r0[:, hi])
                 nd = _needed(probe[vmin], probe[vmax], r1[:, lo], r1[:, hi], r0[:, lo], r0[:, hi])
                 nd = np.where(f0, nd, 0.0)
                 t.needed_by[name] = float(nd.max(initial=0.0))
