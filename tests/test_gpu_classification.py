@@ -98,7 +98,7 @@ def test_adversarial_scenes_per_tile_and_triangle(rt, orc):
 
 def test_c3_every_tile_of_the_benchmarked_frame(rt, orc):
     """BASELINE configs[2] at full size: all 32 400 wave tiles x 32 triangles.  The product's stored lists and certain-winner
-    verdicts (51.9 % of the tiles) are cross-checked tile by tile; every tile is probed with 65 lens samples, every 8th
+    verdicts (67.4 % of the tiles) are cross-checked tile by tile; every tile is probed with 65 lens samples, every 8th
     with the full set."""
     from raytracertest_amd import scenes
     cfg = scenes.CONFIGS["C3"]
@@ -118,7 +118,7 @@ def test_c3_every_tile_of_the_benchmarked_frame(rt, orc):
     s = clean(t, "C3 all tiles")
     s2 = clean(t2, "C3 every 8th tile, full lens set")
     REPORT["C3_all_tiles"], REPORT["C3_every_8th_tile_full_lens_and_ladder"] = s, s2
-    assert t.regions == 32400 and t.sure_tiles > 15000 and t.dropped > 0.9 * t.pairs
+    assert t.regions == 32400 and t.sure_tiles > 21000 and t.dropped > 0.9 * t.pairs
 
 
 def test_c4_scene_all_three_levels_and_the_forms(rt, orc):

@@ -259,3 +259,76 @@ def test_dense_scene_macro_lists_are_kept_between_launches_and_rebuilt_on_change
     same()
     assert np.array_equal(g.Image(), o.image)
     g.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_certain_winner_table_follows_sample_count_scene_and_launch_kind(rt, orc, mode):
+    """Tiles with a certain winner read what their samples add up to -- and, on cleared accumulators, their BGRA8 word -- from
+    a per-triangle table built for the launch's sample count (rtk::sure_table_kernel).  Back-to-back launches with changing
+    sample counts (the table is rewritten while earlier launches may still be in flight), clearing / accumulating / emitting
+    launches, fused iterations, a second scene and the table switched off all end bit-identical to the oracle."""
+    import ctypes as C
+    from oracle import oracle_py
+    from raytracertest_amd import scenes
+    W, H = 192, 136                                                    # split launches (>= 128 rows)
+    g = rt.RayTracer((W, H), (0, 0, 0), (0.0, 0.0), 70.0, 3.0, 0.05, seed=6, math_mode=mode)
+    o = orc.OracleTracer(W, H, (0.0, 0.0), 70.0, 3.0, 0.05, seed=6, contract=1 - mode, nthreads=8)
+    scn = scenes.cornell32()
+    assert g.UploadScene(scn) and o.upload_scene(scn)
+
+    def same(image=False):
+        g.Sync()
+        assert np.array_equal(g.SampleCounts(), o.counts)
+        assert np.array_equal(g.RngStates(), o.rng), "RNG states"
+        assert np.array_equal(g.RenderBuffer().view(np.uint32), o.render.view(np.uint32)), "render buffer"
+        if image:
+            oracle_py.lib().orc_convert(C.byref(o._frame))            # Kernels.cuh:149-169 on the oracle's accumulators
+            assert np.array_equal(g.Image(), o.image), "BGRA8 image"
+
+    g.Trace(1, 16, 0); assert g.Wait(); o.trace(1, 16)                 # cleared accumulators + emit: the table's BGRA8 word
+    words = g.DebugTileListWords()[:, :, 0]
+    assert ((words >> 31) != 0).mean() > 0.3, "the frame has certain-winner tiles"
+    same(image=True)
+    seq = [1, 4, 16, 3, 16, 0, 5, 5, 2]
+    g.Launch(seq[0], clear_first=True); o.trace(0, 0); o.launch(seq[0])
+    for s in seq[1:]:
+        g.Launch(s); o.launch(s)                                       # accumulating, no host sync in between
+    same()
+    g.Launch(7, emit_image=True); o.launch(7)                          # emit on accumulated buffers: converted per pixel
+    same(image=True)
+    g.Launch(6, clear_first=True, emit_image=True); o.trace(0, 0); o.launch(6)
+    same(image=True)
+    g.Trace(5, 3, 0); assert g.Wait(); o.trace(5, 3)                   # fused iterations of a Trace nobody observes
+    same(image=True)
+    big = np.array([[-50, -50, -4, 0], [50, -50, -4, 0], [0, 90, -4, 0], [-1, -1, -2, 0], [1, -1, -2, 0], [0, 1, -2, 0]], np.float32)
+    assert g.UploadScene(big) and o.upload_scene(big)                  # another scene, same sample count: the table follows
+    g.Trace(2, 3, 0); assert g.Wait(); o.trace(2, 3)
+    same(image=True)
+    g.close()
+
+
+def test_certain_winner_table_can_be_switched_off(rt, orc, monkeypatch):
+    """RT_MI355X_NO_SURE_TABLE=1 (the additions done per pixel): the same bits."""
+    from raytracertest_amd import scenes
+    import subprocess, sys, os
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+import raytracertest_amd as R
+from raytracertest_amd import scenes
+g = R.RayTracer((192, 136), (0, 0, 0), (0.0, 0.0), 70.0, 3.0, 0.05, seed=6)
+g.UploadScene(scenes.cornell32()); g.Trace(2, 9, 0); g.Wait()
+import zlib
+print(zlib.crc32(g.RenderBuffer().tobytes()), zlib.crc32(g.RngStates().tobytes()), zlib.crc32(g.Image().tobytes()))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for off in ("0", "1"):
+        env = dict(os.environ, RT_MI355X_NO_SURE_TABLE=off)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1], outs
+    o = orc.OracleTracer(192, 136, (0.0, 0.0), 70.0, 3.0, 0.05, seed=6, contract=1, nthreads=8)
+    o.upload_scene(scenes.cornell32()); o.trace(2, 9)
+    import zlib
+    assert outs[0] == "%d %d %d" % (zlib.crc32(o.render.tobytes()), zlib.crc32(o.rng.tobytes()), zlib.crc32(o.image.tobytes()))
