@@ -232,7 +232,12 @@ __global__ __launch_bounds__(256) void dbg_classify_kernel(const TraceParams p, 
 #pragma unroll
       for (int i = 0; i < 18; ++i) forms[i] = 0.0f;
       bool keep = true;
-      if (fam.usable) keep = !tile_misses_triangle<true, false, SL>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z}, forms, nullptr, nullptr, ends);
+      if (fam.usable) {     // as the trace wave does it: the S rules as a call of their own, then the forms call (whose ends are exported)
+        float ends3[10] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        const bool miss3 = tile_misses_triangle<false, false, SL, true>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z}, nullptr, nullptr, nullptr, ends3);
+        keep = !tile_misses_triangle<true, false, SL>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z}, forms, nullptr, nullptr, ends) && !miss3;
+        ends[8] = ends3[8]; ends[9] = ends3[9];
+      }
       r[0] = keep ? 1.0f : 0.0f;
 #pragma unroll
       for (int i = 0; i < 6; ++i) r[1 + i] = ends[i];

@@ -450,6 +450,9 @@ __device__ __forceinline__ TileFamily make_family(const TraceParams& p, const Fo
 // the nearest-hit rule, which need t, u, v.)
 // dbg (harness only, null in every product call): the interval ends the verdicts are taken from --
 // {det_lo, det_hi, U_lo, U_hi, V_lo, V_hi, Nt_lo, Nt_hi, S_lo, S_hi} (Nt only with SURE; S' = det' - U' - V').
+#ifndef RT_LISTS_WAVES
+#define RT_LISTS_WAVES 5      // region_lists_kernel: waves per SIMD the allocator must allow (its VGPRs are taken from the trace waves it runs beside)
+#endif
 #ifndef RT_TRACE_THIRD_BLOCK
 #define RT_TRACE_THIRD_BLOCK true
 #endif
@@ -458,7 +461,8 @@ __device__ __forceinline__ TileFamily make_family(const TraceParams& p, const Fo
 #endif
 template <bool FORMS = false, bool SURE = false, class SL = SlackProduct, bool THIRD = !FORMS>
 __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0, V3 e1, V3 e2, float* forms = nullptr,
-                                                     bool* sure_hit = nullptr, float* q = nullptr, float* dbg = nullptr) {
+                                                     bool* sure_hit = nullptr, float* q = nullptr, float* dbg = nullptr,
+                                                     float* pair = nullptr) {
   // rounding allowance relative to the magnitude sums (DESIGN.md 4.1 "Rounding budget": <= ~20 half-ulps are
   // needed, 67 / 84 are charged).  RT_BIN_SLACK_SCALE exists for the teeth test of the adversarial campaign only
   // (tools/stress_boundaries.py against a build with the allowance scaled down must FIND mismatches).
@@ -483,6 +487,7 @@ __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0,
   float DR = 0.0f, UR = 0.0f, VR = 0.0f;                            // FORMS: radii for a known origin
   float tmag = 0.0f;                                                // SURE: >= |dot(e2, (o - v0) x e1)|
   float Ntc = 0.0f, Nt_rad = 0.0f;                                  // SURE: Nt = -(o - v0).N at the lens centre, radius over the lens
+  float wn = 0.0f;                                                  // SURE, pair: the magnitude sum of det' (its rounding allowance is c * wn)
   float Nv[3] = {0.0f, 0.0f, 0.0f}, Gu[3] = {0.0f, 0.0f, 0.0f}, Gv[3] = {0.0f, 0.0f, 0.0f};
   float Eu[3] = {0.0f, 0.0f, 0.0f}, Ev[3] = {0.0f, 0.0f, 0.0f}, qd[3] = {0.0f, 0.0f, 0.0f};
   float cn[3], cu[3], cv[3];                                        // |coefficient| of do_i in det', U', V' (lens terms)
@@ -523,6 +528,7 @@ __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0,
       tmag += E2[i] * Txe1;
       Ntc -= tvc[i] * N_i;
       Nt_rad += a[i] * __builtin_fabsf(N_i);
+      if (pair != nullptr) { pair[2 + i] = N_i; wn += W[i] * Nabs; }
     }
     if constexpr (FORMS) {
       // a_r: what is left of |do_i| once the sample's own origin is used -- the roundings of o = pos + off
@@ -618,6 +624,12 @@ __device__ __forceinline__ bool tile_misses_triangle(const TileFamily& f, V3 v0,
     const float inv_lo = __builtin_amdgcn_rcpf(det_lo), inv_hi = __builtin_amdgcn_rcpf(det_hi);   // (1 ulp: far inside the 1e-4 margin of the comparison)
     q[0] = (nt_lo >= 0.0f) ? nt_lo * inv_hi : nt_lo * inv_lo;
     q[1] = (det_lo > 0.0f) ? ((nt_hi >= 0.0f) ? nt_hi * inv_lo : nt_hi * inv_hi) : __builtin_inff();
+    if (pair != nullptr) {          // what pair_farther() needs of this triangle: the polynomials' centres, gradient and allowances
+      pair[0] = Ntc; pair[1] = detc;                                 // Nt = Ntc - do.N, det' = detc + (dF - do).N; pair[2..4] = N
+      pair[5] = c * tmag; pair[6] = c * wn;                          // allowances for the reference's Nt |w| and det |w|
+      pair[7] = fmaxf(__builtin_fabsf(nt_lo), __builtin_fabsf(nt_hi));   // >= |Nt| over the family
+      pair[8] = fmaxf(__builtin_fabsf(det_lo), __builtin_fabsf(det_hi)); // >= |det'|
+    }
   }
   const bool all_culled = det_hi < RT_EPS * f.lmin;
   const bool pos = det_hi > 0.0f;
@@ -987,6 +999,33 @@ __device__ __forceinline__ void region_focal_bounds(const TraceParams& p, uint32
   }
 }
 
+// Is A farther than B for every ray of the family that hits both?  The reference's t = dot(e2, qv) / det (Kernels.cuh:63) is
+// Nt |w| / det' with Nt = Ntc - do.N and det' = detc + (dF - do).N, both per triangle; two candidates of one ray share |w|, so
+// with both det' > 0 (A certainly hit, B hit by this ray)  t_A > t_B  <=>  D = Nt_A det'_B - Nt_B det'_A > 0.
+//     D = Dc + dF.gF + do.gO + (do x dF).(N_B x N_A)      gF = nA N_B - nB N_A      gO = -gF - dB N_A + dA N_B
+// -- affine in the lens offset and the focal offset but for one small bilinear term, where the per-triangle q intervals
+// of two triangles at similar depth (a box on the floor, a light under the ceiling) overlap however tight they are.  Charged:
+// the radii over |do_i| <= orad_i, |dF_i| <= frad_i; the reference's evaluation of the four factors (the allowances of the
+// q bounds, cross-multiplied with the bounds of the other factor); 1e-4 relative for the roundings of the two quotients and
+// of this evaluation, as the q comparison does.  a, b: pair[] of tile_misses_triangle.  Any NaN: false.
+template <class SL>
+__device__ __forceinline__ bool pair_farther(const TileFamily& f, const float* a, const float* b) {
+  const float nA = a[0], dA = a[1], nB = b[0], dB = b[1];
+  const float Dc = nA * dB - nB * dA;
+  float rad = 0.0f, gFv[3], gOv[3], cr[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int j = (i + 1) % 3, k = (i + 2) % 3;
+    gFv[i] = nA * b[2 + i] - nB * a[2 + i];
+    gOv[i] = (dA * b[2 + i] - dB * a[2 + i]) - gFv[i];
+    cr[i] = __builtin_fabsf(b[2 + j] * a[2 + k] - a[2 + j] * b[2 + k]);   // |(N_B x N_A)_i|
+    rad += f.frad[i] * __builtin_fabsf(gFv[i]) + f.orad[i] * __builtin_fabsf(gOv[i]) + cr[i] * (f.orad[j] * f.frad[k] + f.orad[k] * f.frad[j]);
+  }
+  const float rnd = (a[5] * b[8] + a[7] * b[6]) + (b[5] * a[8] + b[7] * a[6]) + a[5] * b[6] + b[5] * a[6];
+  const float mag = a[7] * b[8] + b[7] * a[8];
+  return (Dc - (rad + rnd) * RT_SLKM(1e-5f)) - 1e-4f * mag > 0.0f;
+}
+
 // 8-lane groups: max in every lane of the group (quad_perm x 2, row_half_mirror)
 __device__ __forceinline__ float max8(float v) {
   v = fmaxf(v, dpp_f<0xB1>(v));
@@ -996,7 +1035,7 @@ __device__ __forceinline__ float max8(float v) {
 }
 
 template <bool FMA, class SL = SlackProduct>
-__global__ __launch_bounds__(256, 5) void region_lists_kernel(const TraceParams p) {
+__global__ __launch_bounds__(256, RT_LISTS_WAVES) void region_lists_kernel(const TraceParams p) {
   __shared__ uint32_t s_cand[4][256];                               // per wave: the region's candidates, ascending
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t gx = (p.W + 31u) / 32u, gy = (p.rows + 7u) / 8u, gry = (gy + 1u) / 2u;
@@ -1051,6 +1090,8 @@ __global__ __launch_bounds__(256, 5) void region_lists_kernel(const TraceParams 
   float Q = NEG, M1 = NEG, M2 = NEG;
   uint32_t A = 0, I1 = 0xFFFFFFFFu;
   const uint32_t gsh = lane & 56u;                                   // first lane of this 8-lane group
+  const bool one_pass = cnt <= 8u;                                   // every candidate of the region has a lane: pairs can be compared
+  bool others_ok = true;                                             // one_pass: every other kept triangle is certainly nearer than A
   for (uint32_t c0 = 0; c0 < cnt; c0 += 8u) {                        // (wave-uniform trip count)
     const bool has = tile_valid && c0 + j < cnt;
     const uint32_t tri = cand[(c0 + j < cnt) ? c0 + j : 0u];
@@ -1058,8 +1099,10 @@ __global__ __launch_bounds__(256, 5) void region_lists_kernel(const TraceParams 
     const float bz = p.tri_b[tri];
     bool keep = has, sure = false;
     float q[2] = {0.0f, 0.0f};
+    float pr[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     if (fam.usable) {
-      const bool miss = tile_misses_triangle<false, true, SL>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z}, nullptr, &sure, q);
+      const bool miss = tile_misses_triangle<false, true, SL>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z}, nullptr, &sure, q,
+                                                              nullptr, pr);
       keep = has && !miss;
     }
     const uint32_t gm = static_cast<uint32_t>(__builtin_amdgcn_ballot_w64(keep) >> gsh) & 0xFFu;
@@ -1071,6 +1114,20 @@ __global__ __launch_bounds__(256, 5) void region_lists_kernel(const TraceParams 
     const uint32_t gbm = static_cast<uint32_t>(__builtin_amdgcn_ballot_w64(cd && q[0] == Qs) >> gsh) & 0xFFu;
     if (gbm != 0u && (!haveA || Qs > Q)) { haveA = true; Q = Qs; A = cand[c0 + static_cast<uint32_t>(__builtin_ctz(gbm))]; }
     const float qh = keep ? ((q[1] == q[1]) ? q[1] : __builtin_inff()) : NEG;
+    if (one_pass) {
+      // A's rivals one by one: nearer by the q intervals, or -- where those overlap -- by the pairwise bound (pair_farther)
+      const uint32_t la = gbm != 0u ? static_cast<uint32_t>(__builtin_ctz(gbm)) : 0xFFFFFFFFu;
+      bool lane_ok = !keep || j == la || (gbm != 0u && qh < Qs - 1e-4f * (__builtin_fabsf(qh) + __builtin_fabsf(Qs)));
+      const bool need = gbm != 0u && !lane_ok;
+      if (__builtin_amdgcn_ballot_w64(need) != 0ull) {               // (wave-uniform: rare)
+        float pa[9];
+        const int src = static_cast<int>(gsh + (la & 7u));
+#pragma unroll
+        for (int i = 0; i < 9; ++i) pa[i] = __shfl(pr[i], src, 64);
+        lane_ok = lane_ok || (need && pair_farther<SL>(fam, pa, pr));
+      }
+      others_ok = (static_cast<uint32_t>(__builtin_amdgcn_ballot_w64(!lane_ok) >> gsh) & 0xFFu) == 0u;
+    }
     const float m1s = max8(qh);
     const uint32_t gtm = static_cast<uint32_t>(__builtin_amdgcn_ballot_w64(keep && qh == m1s) >> gsh) & 0xFFu;
     const uint32_t l1 = gtm != 0u ? static_cast<uint32_t>(__builtin_ctz(gtm)) : 0xFFFFFFFFu;
@@ -1085,6 +1142,7 @@ __global__ __launch_bounds__(256, 5) void region_lists_kernel(const TraceParams 
   if (haveA) {
     const float R = (I1 == A) ? M2 : M1;                             // the largest upper bound among the OTHER kept triangles
     sure_one = count <= 1u || (R < Q - 1e-4f * (__builtin_fabsf(R) + __builtin_fabsf(Q)));
+    if (one_pass) sure_one = sure_one || others_ok;                  // (others_ok alone would do: the line above is what it generalises)
   }
   if (j == 0u) {
     if (tile_valid) saved[0] = count | (A << 10) | (sure_one ? 0x80000000u : 0u);
@@ -1162,9 +1220,10 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   // is requested behind the classification instead (one exposed load latency per wave, hidden by the other three waves).
   constexpr bool RNG_LATE = PRE && BIN && !ONEPASS;
   // The third-edge rules of tile_misses_triangle inside this kernel (block and wave level of dense scenes; the macro level and the
-  // small scenes' list builders always have them): at the block level always, at the wave level not in the instantiations with
-  // the per-sample forms, whose F3 is the same rule per ray and whose 128-VGPR budget the extra sums overflow (K = 4: 24 -> 92
-  // bytes of scratch per lane).  C4, interleaved on one device: macro level only 3.97 ms, + block level 3.75 ms, + wave level 4.55 ms.
+  // small scenes' list builders always have them): at the block level always; at the wave level of the instantiations with the
+  // per-sample forms not inside the forms call (K = 4: 24 -> 92 bytes of scratch per lane) but as a separate call in front
+  // of it.  C4, interleaved on one device: macro level only 3.97 ms, + block level 3.75 ms, + wave level inside the forms
+  // call 4.55 ms, as a call of its own 3.68 ms.
   constexpr bool THIRD_BLOCK = RT_TRACE_THIRD_BLOCK, THIRD_WAVE = RT_TRACE_THIRD_WAVE;
   if constexpr (!RNG_LATE) load_rng();
 
@@ -1319,7 +1378,15 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
                          0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};   // all-zero forms never reject
       if (fam.usable) {
         if constexpr (PRETEST && WF) {
-          if (pretest) keep = valid && !tile_misses_triangle<true>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z}, forms);
+          if (pretest) {
+            // The rules on S' = det' - U' - V' as a call of their own in front of the forms: inside the forms call their sums
+            // overflow the register budget (92 instead of 24 bytes of scratch, 4.47 instead of 3.75 ms at C4); the triangle's
+            // values are laundered in between so that the two calls share no live ranges.  C4: 9.5 -> 8.8 candidates per
+            // tile, 3.75 -> 3.68 ms.
+            const bool miss3 = tile_misses_triangle<false, false, SlackProduct, true>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z});
+            asm volatile("" : "+v"(A0.x), "+v"(A0.y), "+v"(A0.z), "+v"(A0.w), "+v"(A1.x), "+v"(A1.y), "+v"(A1.z), "+v"(A1.w), "+v"(bz));
+            keep = valid && !miss3 && !tile_misses_triangle<true>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z}, forms);
+          }
           else keep = valid && !tile_misses_triangle<false, false, SlackProduct, THIRD_WAVE>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z});
         } else {
           keep = valid && !tile_misses_triangle<false, false, SlackProduct, THIRD_WAVE>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z});

@@ -101,11 +101,12 @@ class Tally:
         self.needed_by = {"det": 0.0, "U": 0.0, "V": 0.0, "S": 0.0}
         self.needed_q = 0.0             # how much of the 1e-4 margin of the winner rule the q bounds use
         self.nan_pairs = 0
+        self.pair_tiles = 0             # certain-winner tiles the product proved with the pairwise bound (beyond the interval rule)
         self.examples = []
 
     def merge(self, o):
         for k in ("regions", "pairs", "rays", "dropped", "kept", "sure", "sure_tiles", "contain_bad", "q_bad", "form_wrong",
-                  "form_rejects", "form_tests", "nan_pairs"):
+                  "form_rejects", "form_tests", "nan_pairs", "pair_tiles"):
             setattr(self, k, getattr(self, k) + getattr(o, k))
         for s in LADDER:
             for k in self.bad[s]:
@@ -131,7 +132,7 @@ class Tally:
     def summary(self):
         return {"regions": self.regions, "tile_triangle_pairs": self.pairs, "rays_per_pair_total": self.rays,
                 "dropped_pairs": self.dropped, "kept_pairs": self.kept, "certainly_hit_pairs": self.sure,
-                "certain_winner_tiles": self.sure_tiles,
+                "certain_winner_tiles": self.sure_tiles, "of_those_by_the_pairwise_bound": self.pair_tiles,
                 "violations_by_scale": {str(s / 1000.0): dict(self.bad[s]) for s in LADDER if s in self.scales},
                 "smallest_passing_scale": self.smallest_passing_scale(),
                 "containment_violations_at_scale_1": self.contain_bad, "q_violations_at_scale_1": self.q_bad,
@@ -206,7 +207,13 @@ def check_region(tag, probe, nohit, rays, recs, hdrs, forms=False, tile_word=Non
             rec_p = recs[1000].copy()
             rec_p[~pk, 0] = 0.0                                # the winner rule over the product's candidates
             hw = certain_winner(rec_p, usable) if n <= SURE_MAX_TRIS else None
-            assert pflag == (hw is not None) and (not pflag or pw == hw), "%s: stored certain-winner verdict (%s, %d) vs harness %s" % (tag, pflag, pw, hw)
+            # the interval rule implies the product's verdict; the product may also order A's rivals pairwise (pair_farther,
+            # not re-derived here): such a verdict is judged by the rays alone, like every other (tile_winner below)
+            assert (hw is None or (pflag and pw == hw)), "%s: stored certain-winner verdict (%s, %d) vs harness %s" % (tag, pflag, pw, hw)
+            if pflag and hw is None:
+                t.pair_tiles += 1
+                f1 = recs[1000][:, 0].astype(np.int32)
+                assert (f1[pw] & 3) == 3, "%s: stored winner %d is not a kept, certainly-hit triangle of the tile-level verdicts" % (tag, pw)
             b["tile_winner"] = int(pflag and wins[pw] != rays)
             t.sure_tiles = int(pflag)
             if (b["drop_hit"] or b["tile_winner"]) and len(t.examples) < 12:
