@@ -186,8 +186,8 @@ def adversarial_triangles(rng, cam, W, H, n, scale, kinds_p=KINDS_DEFAULT):
 
 def cover_config(rng):
     """A configuration aimed at the certain-winner verdict: a few to 64 triangles, most of them covering a tile's whole
-    ray family by a margin of 0 ... 1 of its size, half of those stacked 0 ... 1e-2 apart in depth; moderate apertures so
-    that covers exist at all."""
+    ray family by a margin of 0 ... 1 of its size, half of those stacked 0 ... 1e-2 apart in depth; backdrops with slightly
+    turned and shifted rivals (the pairwise ordering of certain winners); moderate apertures so that covers exist at all."""
     scale = float(10.0 ** rng.uniform(-3, 4))
     W, H = int(rng.integers(9, 73)), int(rng.integers(9, 49))
     cam = dict(angles=(float(rng.uniform(-3.2, 3.2)), float(rng.uniform(-3.2, 3.2))), fov=float(rng.uniform(5, 120)),
@@ -213,6 +213,23 @@ def cover_config(rng):
             if e1 @ np.cross(dcen, e2) < 0.0:                                    # det > 0: the camera-facing winding
                 tri = tri[[0, 2, 1]]
             back.append(tri)
+            if rng.uniform() < 0.6:
+                # a RIVAL of the backdrop: the same triangle turned by a small angle about an axis through a point of the view
+                # and shifted in depth by nothing ... 1e-2 of its distance -- the two q intervals overlap, the planes may cross
+                # inside a tile's footprint (no winner can be certain there) or not (the pairwise bound may order them);
+                # scanned before or after the backdrop (ties go to the first scanned, Kernels.cuh:84)
+                ang = float(rng.choice([0.0, 1e-6, 1e-4, 1e-3, 1e-2, 1e-1])) * float(rng.choice([-1.0, 1.0]))
+                axis = a if rng.integers(0, 2) else b
+                piv = cen + (a * rng.uniform(-1, 1) + b * rng.uniform(-1, 1)) * half * float(rng.choice([0.0, 0.3, 1.5]))
+                c_, s_ = np.cos(ang), np.sin(ang)
+                rel = tri - piv
+                rot = rel * c_ + np.cross(axis, rel) * s_ + axis * (rel @ axis)[:, None] * (1.0 - c_)      # Rodrigues
+                shift = dcen * T * float(rng.choice([0.0, 1e-7, 1e-5, 1e-3, 1e-2])) * float(rng.choice([-1.0, 1.0]))
+                rival = piv + rot + shift
+                if rng.integers(0, 2):
+                    back.insert(len(back) - 1, rival)
+                else:
+                    back.append(rival)
         tris = np.concatenate([tris, np.nan_to_num(np.array(back), posinf=3e38, neginf=-3e38).astype(np.float32)])
     return dict(scale=scale, W=W, H=H, cam=cam, tris=tris, mode=int(rng.integers(0, 2)), spp=int(rng.integers(1, 9)),
                 iters=int(rng.integers(1, 3)), seed=int(rng.integers(1, 1 << 30)), nearest=False)
