@@ -588,6 +588,7 @@ struct rt_tracer {
   // RT_MI355X_LISTS_INLINE=1: build on the trace streams, one slot (A/B).
   static constexpr int kListRing = 8, kFreeEvents = 10;
   int ring_n = 8, kFreeStride = 4;    // RT_MI355X_LIST_RING=slots:stride (A/B; stride <= slots - 2, or 1)
+  bool ring_from_env = false;
   uint32_t* d_list_ring[kListRing] = {};
   hipEvent_t list_ready[kListRing] = {};
   hipEvent_t list_free_a[kFreeEvents] = {}, list_free_b[kFreeEvents] = {};
@@ -631,6 +632,10 @@ struct rt_tracer {
       HIP_CHECK(hipStreamSynchronize(main_stream()));
       sync_list_stream();
       release_tile_lists();
+      if (!ring_from_env) {                                              // long lists on large frames: a shorter ring (<= 1 GiB of lists)
+        const bool big = words * sizeof(uint32_t) > (size_t(128) << 20);
+        ring_n = big ? 4 : 8; kFreeStride = big ? 2 : 4;
+      }
       for (int r = 0; r < (lists_inline ? 1 : ring_n); ++r) {
         HIP_CHECK(hipMalloc(&d_list_ring[r], words * sizeof(uint32_t)));
         // count 0 everywhere until a launch builds; on the stream the builds run on (a hipMemset on the null stream is not
@@ -1047,7 +1052,7 @@ int rt_tracer_create_ex(const uint32_t imageSize[2], const float cameraPosition[
   { const char* ns = getenv("RT_MI355X_NO_SPLIT"); t->split_launches = !(ns && ns[0] == '1'); }
   if (const char* lr = getenv("RT_MI355X_LIST_RING")) {
     int n = 0, st = 0;
-    if (sscanf(lr, "%d:%d", &n, &st) == 2 && n >= 3 && n <= rt_tracer::kListRing && st >= 1 && (st == 1 || st <= n - 2)) { t->ring_n = n; t->kFreeStride = st; }
+    if (sscanf(lr, "%d:%d", &n, &st) == 2 && n >= 3 && n <= rt_tracer::kListRing && st >= 1 && (st == 1 || st <= n - 2)) { t->ring_n = n; t->kFreeStride = st; t->ring_from_env = true; }
   }
   if (const char* es = getenv("RT_MI355X_EVENT_STRIDE")) t->event_stride = static_cast<uint32_t>(strtoul(es, nullptr, 10));
   {

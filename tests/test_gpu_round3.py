@@ -332,3 +332,27 @@ print(zlib.crc32(g.RenderBuffer().tobytes()), zlib.crc32(g.RngStates().tobytes()
     o.upload_scene(scenes.cornell32()); o.trace(2, 9)
     import zlib
     assert outs[0] == "%d %d %d" % (zlib.crc32(o.render.tobytes()), zlib.crc32(o.rng.tobytes()), zlib.crc32(o.image.tobytes()))
+
+
+def test_long_lists_on_a_large_frame_use_the_short_ring(rt, orc):
+    """A list buffer above 128 MiB (960-record lists on a 2048x1200 frame) gets a ring of 4 slots with a free event every
+    2nd build instead of 8 : 4.  Twelve Traces with the lists rebuilt by each (the ring wraps three times) end bit-identical
+    to the oracle on sampled row bands."""
+    from raytracertest_amd import scenes
+    W, H = 2048, 1200
+    scn = scenes.random_triangles(300, 11)
+    g = rt.RayTracer((W, H), (0, 0, 0), (0.0, 0.0), 70.0, 3.0, 0.03, seed=9, bin_list=960)
+    assert g.UploadScene(scn)
+    g.SetListReuse(False)
+    for _ in range(12):
+        g.TraceEnqueue(1, 1)
+    g.Sync()
+    render, rng_states = g.RenderBuffer(), g.RngStates()
+    for row0 in (0, 592, 1184):
+        o = orc.OracleTracer(W, H, (0.0, 0.0), 70.0, 3.0, 0.03, seed=9, contract=1, nthreads=8, row0=row0, rows=16)
+        assert o.upload_scene(scn)
+        for _ in range(12):
+            o.trace(1, 1)
+        assert np.array_equal(render[row0:row0 + 16].view(np.uint32), o.render.view(np.uint32)), "rows %d.." % row0
+        assert np.array_equal(rng_states[row0:row0 + 16], o.rng), "RNG states, rows %d.." % row0
+    g.close()
