@@ -367,7 +367,13 @@ hipError_t launch_trace(const TraceParams& p, bool fma, bool filter, bool bin, i
   const bool ordered = p.block_order != nullptr && p.iters <= 1u && p.stats == nullptr;
   if (p.block_order != nullptr && !ordered) return hipErrorInvalidValue;
   if (ordered && p.block_count == 0u) return hipSuccess;
-  const dim3 grid = ordered ? dim3(p.block_count, 1) : dim3(cdiv(p.W, 32), cdiv(p.rows, 8));
+  dim3 grid = ordered ? dim3(p.block_count, 1) : dim3(cdiv(p.W, 32), cdiv(p.rows, 8));
+  if (!ordered && p.row_il != 0u) {                                  // every second block row (small-scene kernels only)
+    if (!(bin && p.n_tris <= p.bin_list) || p.stats != nullptr) return hipErrorInvalidValue;
+    const uint32_t R = grid.y, G = p.row_il, full = R / (2u * G), rest = R % (2u * G);      // groups of G block rows, alternating
+    grid.y = full * G + (p.row_phase == 0u ? (rest < G ? rest : G) : (rest > G ? rest - G : 0u));
+    if (grid.y == 0u) return hipSuccess;
+  }
   const size_t lds = trace_lds_bytes(p, bin) + p.lds_pad;
   if (p.iters > 1u) {                // fused iterations: default (filtered, classified, un-instrumented) kernels only
     if (!trace_can_fuse(filter, bin) || p.stats != nullptr) return hipErrorInvalidValue;
@@ -438,6 +444,17 @@ __global__ __launch_bounds__(256) void sure_table_kernel(const float4* __restric
   const float c = static_cast<float>(samples);
   const uint32_t bgra = rtd::pack_color(255.0f * (acc.x / c), 255.0f * (acc.y / c), 255.0f * (acc.z / c));
   out[tri] = make_float4(ax, ay, az, __builtin_bit_cast(float, bgra));
+}
+
+__global__ void publish_half_cost_kernel(uint32_t* __restrict__ half_cost, unsigned long long* __restrict__ host_word) {
+  const unsigned long long u = half_cost[0], l = half_cost[1];
+  half_cost[0] = 0u; half_cost[1] = 0u;
+  *reinterpret_cast<volatile unsigned long long*>(host_word) = u | (l << 32);
+}
+
+hipError_t launch_publish_half_cost(uint32_t* half_cost, unsigned long long* host_word, hipStream_t st) {
+  hipLaunchKernelGGL(publish_half_cost_kernel, dim3(1), dim3(1), 0, st, half_cost, host_word);
+  return hipGetLastError();
 }
 
 hipError_t launch_sure_table(const float4* colors, uint32_t n_tris, uint32_t samples, float4* out, hipStream_t st) {

@@ -51,6 +51,13 @@ struct TraceParams {
   // small scenes: the order in which this (half-)launch visits its trace blocks -- entry i = bx | by << 16 of the block that
   // workgroup i (row-major over the grid) works on; null = the grid's own order (the product; rt_dbg_set_block_order is an
   // experiment hook).
+  // small scenes, split launches: this kernel traces every second block row of the band -- block row 2 * blockIdx.y + row_phase --
+  // so that the two kernels of a launch cost the same whatever the picture (row_il = 0: the grid's rows are the band's)
+  uint32_t  row_il, row_phase;
+  // list builder (two-level): tiles that will generate rays, counted per half of the band -- [0]: block rows < cost_split_brow,
+  // [1]: the others (device counters, published to the host by publish_half_cost; null: not counted)
+  uint32_t* half_cost;
+  uint32_t  cost_split_brow;
   const uint32_t* block_order;
   uint32_t  block_count;    // with block_order: entries of this launch (its grid is 1-D: ceil(block_count) workgroups)
   uint32_t  lds_pad;        // experiment: bytes of dynamic LDS added to the launch (caps the blocks per CU)
@@ -91,6 +98,9 @@ hipError_t launch_dbg_hit_triangle(bool fma, uint32_t n, const float* rays, cons
                                    int* hit, float* tuv, float* normal, float* point, hipStream_t st);
 bool trace_can_fuse(bool filter, bool bin);      // launches with TraceParams::iters > 1 are available
 hipError_t launch_macro_bin(const TraceParams& p, bool fma, hipStream_t st);
+// small scenes: hands the builder's per-half counts (TraceParams::half_cost) to the host -- *host_word = upper | lower << 32 --
+// and clears them for the next build
+hipError_t launch_publish_half_cost(uint32_t* half_cost, unsigned long long* host_word, hipStream_t st);
 // small scenes: the per-triangle table TraceParams::sure_table for launches of `samples` samples
 hipError_t launch_sure_table(const float4* colors, uint32_t n_tris, uint32_t samples, float4* out, hipStream_t st);
 // small scenes: the tiles' candidate lists + certain-winner verdicts of the (half-)launch `p` into p.tile_lists

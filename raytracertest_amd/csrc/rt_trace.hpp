@@ -1148,6 +1148,16 @@ __global__ __launch_bounds__(256, RT_LISTS_WAVES) void region_lists_kernel(const
     if (tile_valid) saved[0] = count | (A << 10) | (sure_one ? 0x80000000u : 0u);
     else if (slot_live) p.tile_lists[static_cast<size_t>(tslot) * (1u + p.bin_list)] = 0u;
   }
+  if (p.half_cost != nullptr) {                                      // tiles that will generate rays, per half of the band
+    const bool rays = j == 0u && tile_valid && !sure_one;
+    const bool lower = (ry * 2u + (t8 >> 2)) >= p.cost_split_brow;
+    const uint32_t nu = static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(rays && !lower)));
+    const uint32_t nl = static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(rays && lower)));
+    if (lane == 0u) {
+      if (nu != 0u) atomicAdd(p.half_cost, nu);
+      if (nl != 0u) atomicAdd(p.half_cost + 1, nl);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1179,6 +1189,8 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
       const uint32_t b = p.block_order[blockIdx.x];
       bx = b & 0xFFFFu; by = b >> 16;
       gxb = (p.W + 31u) / 32u;
+    } else if (p.row_il != 0u) {
+      by = (blockIdx.y / p.row_il) * (2u * p.row_il) + p.row_phase * p.row_il + blockIdx.y % p.row_il;
     }
   }
   const uint32_t px = bx * 32u + wave * 8u + (lane & 7u);

@@ -458,7 +458,20 @@ struct rt_tracer {
       // the tracer was idle therefore lets its lower half start behind its upper half: a stagger of one half-frame kernel
       // that has the device to itself, i.e. about half a step, whatever the workload.  Later launches free-run.
       const bool stagger = stagger_next.exchange(false) && !no_stagger;
+      // Small scenes: the halves are the even and the odd block rows of the band, not its upper and lower rows -- two kernels
+      // of the same composition whatever the picture (C3 by rows: the upper 50 / 55 % of the rows 60.5 / 59.3 us per step).
+      // Dense scenes keep row halves (their macro lists are per half, in macro tiles of 8 block rows).
+      const bool interleave = have_lists && !lists_inline && want_interleave();
+      if (have_lists && interleave != rows_interleaved) {                  // pixels change streams: everything before goes first
+        (void)main_stream();
+        fork_b();
+        rows_interleaved = interleave;
+        static const bool log = getenv("RT_MI355X_LOG") != nullptr;
+        if (log) fprintf(stderr, "[rt_mi355x] split launches: halves by %s\n", interleave ? "even / odd block rows" : "rows");
+      }
       rtk::TraceParams half[2] = {sub_band(p, 0u, r0), sub_band(p, r0, p.rows - r0)};
+      static const uint32_t il_group = [] { const char* e = getenv("RT_MI355X_ROW_GROUP"); const long v = e ? strtol(e, nullptr, 10) : 1; return static_cast<uint32_t>(v >= 1 && v <= 64 ? v : 1); }();
+      if (interleave) { half[0] = p; half[1] = p; half[0].row_il = half[1].row_il = il_group; half[1].row_phase = 1u; }
       hipStream_t st[2] = {stream, stream_b};
       if (timed) HIP_CHECK(hipEventRecord(e.a, stream));                 // the sampled duration is the upper half-frame kernel's
       for (int h = 0; h < 2; ++h) {
@@ -604,6 +617,25 @@ struct rt_tracer {
   bool no_stagger = false;                // RT_MI355X_NO_STAGGER=1 (A/B)
   size_t tile_lists_words = 0;
   uint32_t* tile_lists_now() const { return d_list_ring[list_cur]; }
+  // Which halves a split small-scene launch uses: the band's upper and lower rows (best when the two cost the same: C3 61.0
+  // against 62.2 us per step) or its even and odd block rows (the same cost whatever the picture: a tilted camera with 57 % /
+  // 22 % ray-generating tiles above / below the split 62.6 against 70.5 us).  The two-level list builder counts the
+  // ray-generating tiles per half and publishes the pair to pinned host memory behind every build; the enqueueing thread
+  // reads the latest pair (a few launches old: the picture does not jump) and switches with hysteresis -- a switch moves
+  // pixels from one stream to the other, so both streams are joined first.
+  uint32_t* d_half_cost = nullptr;                // two device counters
+  unsigned long long* h_half_cost = nullptr;      // pinned: upper | lower << 32 of the latest finished build
+  bool rows_interleaved = false;
+  int interleave_mode = -1;                       // RT_MI355X_ROW_INTERLEAVE=0/1 pins it (A/B); -1: by the counts
+  bool want_interleave() {
+    if (interleave_mode >= 0) return interleave_mode != 0;
+    if (h_half_cost == nullptr) return false;
+    const unsigned long long w = *reinterpret_cast<volatile unsigned long long*>(h_half_cost);
+    const double u = static_cast<double>(w & 0xFFFFFFFFull), l = static_cast<double>(w >> 32);
+    if (u + l < 16.0) return rows_interleaved;    // nothing (yet) to go by
+    const double ratio = (u > l ? u : l) / ((u > l ? l : u) + 1.0);
+    return rows_interleaved ? ratio > 1.15 : ratio > 1.25;
+  }
   uint32_t split_row(uint32_t band_rows) const {   // first row of the lower half of a split launch (a multiple of 8); 0 = not split
     static const uint32_t split_pct = [] { const char* e = getenv("RT_MI355X_SPLIT_PCT"); const long v = e ? strtol(e, nullptr, 10) : 50; return static_cast<uint32_t>(v >= 10 && v <= 90 ? v : 50); }();
     return (split_launches && band_rows >= 128u) ? ((band_rows * split_pct / 100u + 7u) / 8u) * 8u : 0u;
@@ -722,8 +754,13 @@ struct rt_tracer {
     list_cur = r;
     rtk::TraceParams q = p_band;
     attach_tile_lists(q, true);
+    const uint32_t sr = split_row(rows);
+    // (counted by every 32nd build only: the atomics and the publishing kernel cost 3.5 us per step when every build has
+    //  them -- and nothing to decide when the mode is pinned)
+    if (sr != 0u && d_half_cost != nullptr && interleave_mode < 0 && (m % 32u) == 0u) { q.half_cost = d_half_cost; q.cost_split_brow = sr / 8u; }
     HIP_CHECK(rtk::launch_tile_lists(q, fma, stream_l));
     HIP_CHECK(hipEventRecord(list_ready[r], stream_l));
+    if (q.half_cost != nullptr) HIP_CHECK(rtk::launch_publish_half_cost(d_half_cost, h_half_cost, stream_l));   // (behind list_ready: nobody waits for it)
     ++list_builds;
   }
   // stream `st` (the primary stream or stream_b) is about to run a trace kernel that reads the current lists
@@ -1095,6 +1132,12 @@ int rt_tracer_create_ex(const uint32_t imageSize[2], const float cameraPosition[
           HIP_CHECK(hipStreamCreateWithFlags(&t->stream_l, hipStreamNonBlocking));
       }
       HIP_CHECK(hipEventCreateWithFlags(&t->stagger_event, hipEventDisableTiming));
+      HIP_CHECK(hipMalloc(&t->d_half_cost, 2 * sizeof(uint32_t)));
+      HIP_CHECK(hipMemset(t->d_half_cost, 0, 2 * sizeof(uint32_t)));
+      HIP_CHECK(hipDeviceSynchronize());                                  // (a null-stream memset is not ordered with the list stream)
+      HIP_CHECK(hipHostMalloc(&t->h_half_cost, sizeof(unsigned long long), hipHostMallocDefault));
+      *t->h_half_cost = 0ull;
+      if (const char* ri = getenv("RT_MI355X_ROW_INTERLEAVE")) { if ((ri[0] == '0' || ri[0] == '1') && ri[1] == 0) t->interleave_mode = ri[0] - '0'; }
       { const char* ns2 = getenv("RT_MI355X_NO_STAGGER"); t->no_stagger = ns2 && ns2[0] == '1'; }
       for (int r = 0; r < rt_tracer::kListRing; ++r) HIP_CHECK(hipEventCreateWithFlags(&t->list_ready[r], hipEventDisableTiming));
       for (int r = 0; r < rt_tracer::kFreeEvents; ++r) {
@@ -1157,6 +1200,8 @@ void rt_tracer_destroy(rt_tracer* t) {                                   // RayT
   }
   if (t->stream_l) (void)hipStreamDestroy(t->stream_l);
   if (t->stagger_event) (void)hipEventDestroy(t->stagger_event);
+  if (t->d_half_cost) (void)hipFree(t->d_half_cost);
+  if (t->h_half_cost) (void)hipHostFree(t->h_half_cost);
   for (int h = 0; h < 2; ++h) if (t->d_macro_lists[h]) (void)hipFree(t->d_macro_lists[h]);
   if (t->d_tri_n) (void)hipFree(t->d_tri_n);
   if (t->d_tri) (void)hipFree(t->d_tri);

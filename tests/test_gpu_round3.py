@@ -356,3 +356,44 @@ def test_long_lists_on_a_large_frame_use_the_short_ring(rt, orc):
         assert np.array_equal(render[row0:row0 + 16].view(np.uint32), o.render.view(np.uint32)), "rows %d.." % row0
         assert np.array_equal(rng_states[row0:row0 + 16], o.rng), "RNG states, rows %d.." % row0
     g.close()
+
+
+def test_split_halves_switch_between_rows_and_block_row_interleave(rt, orc):
+    """Split small-scene launches use the band's upper / lower rows or its even / odd block rows, chosen from the list builder's
+    per-half counts of ray-generating tiles (every 32nd build) -- a switch moves pixels between the two streams and joins them
+    first.  A camera that swings between a balanced and a lopsided view while launches stay in flight, and both pinned modes,
+    end bit-identical to the oracle on sampled rows."""
+    import os, subprocess, sys, zlib
+    from raytracertest_amd import scenes
+    W, H = 512, 320
+    code = r"""
+import sys, zlib, numpy as np
+sys.path.insert(0, %r)
+import raytracertest_amd as R
+from raytracertest_amd import scenes
+g = R.RayTracer((512, 320), (0, 0, 0), (0.0, 0.0), 70.0, 3.0, 0.05, seed=5)
+g.UploadScene(scenes.cornell32()); g.SetListReuse(False)
+for k in range(6):
+    for _ in range(40): g.TraceEnqueue(1, 2)            # no host sync in between: the switch happens under launches in flight
+    g.RotateCamera((0.45 if k %% 2 == 0 else -0.45, 0.0))
+g.Sync()
+print(zlib.crc32(g.RenderBuffer().tobytes()), zlib.crc32(g.RngStates().tobytes()), zlib.crc32(g.Image().tobytes()))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for mode in ("", "0", "1"):
+        env = dict(os.environ)
+        env.pop("RT_MI355X_ROW_INTERLEAVE", None)
+        if mode: env["RT_MI355X_ROW_INTERLEAVE"] = mode
+        env["RT_MI355X_LOG"] = "1"
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = r.stdout.strip().splitlines()[-1]
+        if not mode:                                            # the free-running tracer did switch, both ways
+            assert "halves by even / odd block rows" in r.stderr and "halves by rows" in r.stderr, r.stderr[-1500:]
+    assert outs[""] == outs["0"] == outs["1"], outs
+    o = orc.OracleTracer(W, H, (0.0, 0.0), 70.0, 3.0, 0.05, seed=5, contract=1, nthreads=8)
+    o.upload_scene(scenes.cornell32())
+    for k in range(6):
+        for _ in range(40): o.trace(1, 2)
+        o.rotate_camera((0.45 if k % 2 == 0 else -0.45, 0.0))
+    assert outs[""] == "%d %d %d" % (zlib.crc32(o.render.tobytes()), zlib.crc32(o.rng.tobytes()), zlib.crc32(o.image.tobytes()))
