@@ -446,6 +446,23 @@ __global__ __launch_bounds__(256) void sure_table_kernel(const float4* __restric
   out[tri] = make_float4(ax, ay, az, __builtin_bit_cast(float, bgra));
 }
 
+// A stagger without a dependency: the lower half of the first split launch after idle has to start about half a kernel
+// behind the upper half (HISTORY.md, phase regimes).  Waiting for the upper half's END costs the whole kernel with half the
+// device idle; this wave just lets the time pass (s_sleep between reads of the 100 MHz counter; bounded by the trip count).
+__global__ __launch_bounds__(64) void delay_kernel(uint32_t ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  for (uint32_t i = 0; i < 100000u; ++i) {
+    if (__builtin_amdgcn_s_memrealtime() - t0 >= ticks) break;
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+
+hipError_t launch_delay(uint32_t us, hipStream_t st) {
+  if (us == 0u) return hipSuccess;
+  hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, st, (us > 5000u ? 5000u : us) * 100u);
+  return hipGetLastError();
+}
+
 __global__ void publish_half_cost_kernel(uint32_t* __restrict__ half_cost, unsigned long long* __restrict__ host_word) {
   const unsigned long long u = half_cost[0], l = half_cost[1];
   half_cost[0] = 0u; half_cost[1] = 0u;

@@ -98,6 +98,8 @@ hipError_t launch_dbg_hit_triangle(bool fma, uint32_t n, const float* rays, cons
                                    int* hit, float* tuv, float* normal, float* point, hipStream_t st);
 bool trace_can_fuse(bool filter, bool bin);      // launches with TraceParams::iters > 1 are available
 hipError_t launch_macro_bin(const TraceParams& p, bool fma, hipStream_t st);
+// one wave that does nothing for `us` microseconds (bounded): the stagger of the first split launch after the tracer was idle
+hipError_t launch_delay(uint32_t us, hipStream_t st);
 // small scenes: hands the builder's per-half counts (TraceParams::half_cost) to the host -- *host_word = upper | lower << 32 --
 // and clears them for the next build
 hipError_t launch_publish_half_cost(uint32_t* half_cost, unsigned long long* host_word, hipStream_t st);

@@ -478,7 +478,13 @@ struct rt_tracer {
         attach_tile_lists(half[h], have_lists);
         if (build_lists && lists_inline) HIP_CHECK(rtk::launch_tile_lists(half[h], fma, st[h]));   // each half builds the lists of its own rows
         if (have_lists) wait_for_lists(st[h], h == 0 ? list_waited_a : list_waited_b);
-        if (h == 1 && stagger) HIP_CHECK(hipStreamWaitEvent(stream_b, stagger_event, 0));
+        if (h == 1 && stagger) {
+          // half a kernel behind the upper half: by the clock when the tracer knows how long its half-frame kernels take
+          // (0.45 of the last sampled one), else behind the upper half's end
+          const uint32_t us = stagger_by_delay ? static_cast<uint32_t>(last_half_ms.load() * 450.0f) : 0u;
+          if (us >= 5u) HIP_CHECK(rtk::launch_delay(us, stream_b));
+          else HIP_CHECK(hipStreamWaitEvent(stream_b, stagger_event, 0));
+        }
         attach_macro_lists(half[h], h, st[h], (flags & rtk::TRACE_ZERO_ACC) != 0u);
         HIP_CHECK(rtk::launch_trace(half[h], fma, filter, bin, K, st[h]));
         if (h == 0 && stagger) HIP_CHECK(hipEventRecord(stagger_event, stream));
@@ -530,6 +536,7 @@ struct rt_tracer {
       float ms = 0.0f;
       if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
         kernel_ms += ms; kernel_launches += e.launches;
+        if (e.split && e.launches == 1) last_half_ms = ms;
         // what the launch COST: for a split launch from the start of the upper half to the end of the later half (the
         // lower half runs on stream_b; a band whose expensive rows sit there must not look cheap to the load balancer)
         float lower = 0.0f;
@@ -615,6 +622,8 @@ struct rt_tracer {
   std::atomic<bool> stagger_next{true};   // the next split launch starts from an idle tracer: stagger its halves (enqueue_trace_launch)
   hipEvent_t stagger_event = nullptr;
   bool no_stagger = false;                // RT_MI355X_NO_STAGGER=1 (A/B)
+  bool stagger_by_delay = true;           // RT_MI355X_STAGGER_EVENT=1: always behind the upper half's end (A/B)
+  std::atomic<float> last_half_ms{0.0f};  // duration of the last sampled upper half-frame kernel of a split launch
   size_t tile_lists_words = 0;
   uint32_t* tile_lists_now() const { return d_list_ring[list_cur]; }
   // Which halves a split small-scene launch uses: the band's upper and lower rows (best when the two cost the same: C3 61.0
@@ -1139,6 +1148,7 @@ int rt_tracer_create_ex(const uint32_t imageSize[2], const float cameraPosition[
       *t->h_half_cost = 0ull;
       if (const char* ri = getenv("RT_MI355X_ROW_INTERLEAVE")) { if ((ri[0] == '0' || ri[0] == '1') && ri[1] == 0) t->interleave_mode = ri[0] - '0'; }
       { const char* ns2 = getenv("RT_MI355X_NO_STAGGER"); t->no_stagger = ns2 && ns2[0] == '1'; }
+      { const char* se = getenv("RT_MI355X_STAGGER_EVENT"); t->stagger_by_delay = !(se && se[0] == '1'); }
       for (int r = 0; r < rt_tracer::kListRing; ++r) HIP_CHECK(hipEventCreateWithFlags(&t->list_ready[r], hipEventDisableTiming));
       for (int r = 0; r < rt_tracer::kFreeEvents; ++r) {
         HIP_CHECK(hipEventCreateWithFlags(&t->list_free_a[r], hipEventDisableTiming));
