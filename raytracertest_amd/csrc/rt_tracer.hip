@@ -455,11 +455,10 @@ struct rt_tracer {
       // The two halves overlap best in ANTI-phase (one half's drain under the other's bulk); started together -- both
       // released by the same event, or from an idle device -- they can lock IN phase and stay there for a whole run
       // (measured at C3: 93 instead of 80 us per step, profiles/r03_phase_regimes.txt).  The first split launch after
-      // the tracer was idle therefore lets its lower half start behind its upper half: a stagger of one half-frame kernel
-      // that has the device to itself, i.e. about half a step, whatever the workload.  Later launches free-run.
+      // the tracer was idle therefore lets its second kernel start about half a kernel behind its first (a delay wave, or
+      // -- before any kernel has been sampled -- behind the first kernel's end).  Later launches free-run.
       const bool stagger = stagger_next.exchange(false) && !no_stagger;
-      // Small scenes: the halves are the even and the odd block rows of the band, not its upper and lower rows -- two kernels
-      // of the same composition whatever the picture (C3 by rows: the upper 50 / 55 % of the rows 60.5 / 59.3 us per step).
+      // Small scenes: the halves are the band's upper and lower rows or its even and odd block rows (want_interleave()).
       // Dense scenes keep row halves (their macro lists are per half, in macro tiles of 8 block rows).
       const bool interleave = have_lists && !lists_inline && want_interleave();
       if (have_lists && interleave != rows_interleaved) {                  // pixels change streams: everything before goes first
