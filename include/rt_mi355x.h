@@ -326,11 +326,6 @@ int rt_dbg_focal_boxes(rt_tracer* t, float curv_scale, float* boxes, size_t boxe
  *   forms {F1.c0, cx, cy, F2..., F3..., g1.xyz, g2.xyz, g3.xyz} each form scaled by its power of two, the gradients the fp16 values the kernel stores, 2 x 0. */
 int rt_dbg_classify(rt_tracer* t, uint32_t level, uint32_t forms, uint32_t slack_milli, const uint32_t* regions, uint32_t n_regions,
                     float* out, size_t capacity_floats);
-/* experiment hook: the order in which the trace blocks (32 x 8 pixels) of a small-scene launch over the whole band are visited;
- * entries bx | by << 16, n = the band's blocks.  n_first != 0: the launch runs as two kernels on the tracer's two streams, the
- * first n_first entries and the rest (the latter with lds_pad_second more bytes of LDS per block, which caps its blocks per CU).
- * NULL restores the grid order. */
-int rt_dbg_set_block_order(rt_tracer* t, const uint32_t* order, uint32_t n, uint32_t n_first, uint32_t lds_pad_second);
 /* states n*6 {d,v0..v4} advanced in place, out n*m uniforms in (0,1] */
 int rt_dbg_uniform(int device, uint32_t n, uint32_t m, uint32_t* states, float* out);
 /* thin-lens rays of the tracer's current camera for n (x, y) pixels with given RNG states */

@@ -44,7 +44,7 @@ ABI_SYMBOLS = [
     "rt_dbg_rng_init_host",
     "rt_tracer_create_multi", "rt_group_unique_id", "rt_tracer_join_group", "rt_tracer_leave_group",
     "rt_tracer_gather_time", "rt_tracer_band_count", "rt_tracer_band_info",
-    "rt_tracer_join_group_bands", "rt_balance_rows", "rt_tracer_rebalance", "rt_tracer_set_band", "rt_dbg_read_tile_lists", "rt_dbg_focal_boxes", "rt_dbg_classify", "rt_dbg_set_block_order",
+    "rt_tracer_join_group_bands", "rt_balance_rows", "rt_tracer_rebalance", "rt_tracer_set_band", "rt_dbg_read_tile_lists", "rt_dbg_focal_boxes", "rt_dbg_classify",
     "rt_tracer_gather_only", "rt_tracer_group_info",
 ]
 

@@ -364,17 +364,14 @@ hipError_t launch_trace(const TraceParams& p, bool fma, bool filter, bool bin, i
   // render += 0, RNG written back, Kernels.cuh:133-146): the fused clear / BGRA8 emit / list store of the
   // launch still have to happen
   if (p.rows == 0 || p.W == 0) return hipSuccess;
-  const bool ordered = p.block_order != nullptr && p.iters <= 1u && p.stats == nullptr;
-  if (p.block_order != nullptr && !ordered) return hipErrorInvalidValue;
-  if (ordered && p.block_count == 0u) return hipSuccess;
-  dim3 grid = ordered ? dim3(p.block_count, 1) : dim3(cdiv(p.W, 32), cdiv(p.rows, 8));
-  if (!ordered && p.row_il != 0u) {                                  // every second block row (small-scene kernels only)
+  dim3 grid(cdiv(p.W, 32), cdiv(p.rows, 8));
+  if (p.row_il != 0u) {                                  // every second block row (small-scene kernels only)
     if (!(bin && p.n_tris <= p.bin_list) || p.stats != nullptr) return hipErrorInvalidValue;
     const uint32_t R = grid.y, G = p.row_il, full = R / (2u * G), rest = R % (2u * G);      // groups of G block rows, alternating
     grid.y = full * G + (p.row_phase == 0u ? (rest < G ? rest : G) : (rest > G ? rest - G : 0u));
     if (grid.y == 0u) return hipSuccess;
   }
-  const size_t lds = trace_lds_bytes(p, bin) + p.lds_pad;
+  const size_t lds = trace_lds_bytes(p, bin);
   if (p.iters > 1u) {                // fused iterations: default (filtered, classified, un-instrumented) kernels only
     if (!trace_can_fuse(filter, bin) || p.stats != nullptr) return hipErrorInvalidValue;
     if (fma) launch_trace_fused<true>(p, K, grid, lds, st);

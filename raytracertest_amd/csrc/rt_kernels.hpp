@@ -48,9 +48,6 @@ struct TraceParams {
   uint32_t  macro_cap, macro_w, macro_h, macro_nx;
   uint32_t* tile_lists; // small scenes: per wave tile count | winner << 10 | certain << 31, then bin_list triangle indices
                         // (written by tile_lists_kernel, read by the trace kernel); null: no lists (large scene, no triangles)
-  // small scenes: the order in which this (half-)launch visits its trace blocks -- entry i = bx | by << 16 of the block that
-  // workgroup i (row-major over the grid) works on; null = the grid's own order (the product; rt_dbg_set_block_order is an
-  // experiment hook).
   // small scenes, split launches: this kernel traces every second block row of the band -- block row 2 * blockIdx.y + row_phase --
   // so that the two kernels of a launch cost the same whatever the picture (row_il = 0: the grid's rows are the band's)
   uint32_t  row_il, row_phase;
@@ -58,9 +55,6 @@ struct TraceParams {
   // [1]: the others (device counters, published to the host by publish_half_cost; null: not counted)
   uint32_t* half_cost;
   uint32_t  cost_split_brow;
-  const uint32_t* block_order;
-  uint32_t  block_count;    // with block_order: entries of this launch (its grid is 1-D: ceil(block_count) workgroups)
-  uint32_t  lds_pad;        // experiment: bytes of dynamic LDS added to the launch (caps the blocks per CU)
   // small scenes: per triangle, what a pixel of a certain-winner tile accumulates in one launch of p.samples samples --
   // {sum.x, sum.y, sum.z, bits of the BGRA8 word of a freshly cleared pixel} (sure_table_kernel; null: the kernel adds)
   const float4* sure_table;

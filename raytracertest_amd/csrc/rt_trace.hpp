@@ -1181,17 +1181,11 @@ __global__ __launch_bounds__(256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) v
   // (workgroup shape, measured at C3 with the lists rebuilt: 256 threads = one block of four tiles 62.5 us per step; one wave
   //  per workgroup 85.0; two / four blocks per workgroup 67.2 / 75.2; 8 instead of 7 waves per SIMD at 64 VGPRs 63.2)
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  uint32_t bx = blockIdx.x, by = blockIdx.y;                       // the block of 32 x 8 pixels this workgroup traces
-  uint32_t gxb = gridDim.x;                                        // blocks per block row
+  const uint32_t bx = blockIdx.x;                                  // the block of 32 x 8 pixels this workgroup traces
+  uint32_t by = blockIdx.y;
+  const uint32_t gxb = gridDim.x;                                  // blocks per block row
   if constexpr (BIN && ONEPASS) {
-    if (p.block_order != nullptr) {                                // (scalar load: uniform address; 1-D grid)
-      if (blockIdx.x >= p.block_count) return;
-      const uint32_t b = p.block_order[blockIdx.x];
-      bx = b & 0xFFFFu; by = b >> 16;
-      gxb = (p.W + 31u) / 32u;
-    } else if (p.row_il != 0u) {
-      by = (blockIdx.y / p.row_il) * (2u * p.row_il) + p.row_phase * p.row_il + blockIdx.y % p.row_il;
-    }
+    if (p.row_il != 0u) by = (blockIdx.y / p.row_il) * (2u * p.row_il) + p.row_phase * p.row_il + blockIdx.y % p.row_il;
   }
   const uint32_t px = bx * 32u + wave * 8u + (lane & 7u);
   const uint32_t ly = by * 8u + (lane >> 3);

@@ -419,27 +419,10 @@ struct rt_tracer {
     const bool timed = sync_after == 1 || event_stride <= 1u || (launch_counter++ % event_stride) == 0u;
     // Tall frames: upper half on the primary stream, lower half on stream_b (see the fields' comment).
     // The split row is a multiple of 8, each half is a row band of its own (own tile / macro lists).
-    const bool class_split = d_block_order_dbg != nullptr && have_lists && iters == 1u;
-    const uint32_t r0 = (allow_split && !class_split) ? split_row(p.rows) : 0u;
+    const uint32_t r0 = allow_split ? split_row(p.rows) : 0u;
     EventPair e{};
     if (timed) { e = take_events(); e.launches = 1; e.split = r0 != 0u; }
-    if (class_split && dbg_order_first != 0u && allow_split) {
-      // EXPERIMENT: two launches over the whole band, one per slice of the uploaded block order, on the two streams
-      fork_b();
-      if (build_lists && !lists_inline) build_tile_lists_ahead(p);
-      attach_tile_lists(p, have_lists);
-      rtk::TraceParams part[2] = {p, p};
-      part[0].block_count = dbg_order_first;
-      part[1].block_order = p.block_order + dbg_order_first; part[1].block_count = dbg_order_n - dbg_order_first; part[1].lds_pad = dbg_order_pad;
-      hipStream_t st[2] = {stream, stream_b};
-      if (timed) HIP_CHECK(hipEventRecord(e.a, stream));
-      for (int h = 0; h < 2; ++h) {
-        if (have_lists) wait_for_lists(st[h], h == 0 ? list_waited_a : list_waited_b);
-        HIP_CHECK(rtk::launch_trace(part[h], fma, filter, bin, K, st[h]));
-      }
-      if (timed) { e.split = true; HIP_CHECK(hipEventRecord(e.b, stream)); HIP_CHECK(hipEventRecord(e.c, stream_b)); }
-      mark_b_dirty();
-    } else if (r0 == 0u) {
+    if (r0 == 0u) {
       (void)main_stream();                                               // a launch on one stream orders behind both
       if (build_lists && !lists_inline) build_tile_lists_ahead(p);
       attach_tile_lists(p, have_lists);
@@ -706,17 +689,7 @@ struct rt_tracer {
     if (!have) return;
     const size_t slot_base = static_cast<size_t>((W + 31u) / 32u) * ((p.row0 - row0) / 8u) * 4u;
     p.tile_lists = tile_lists_now() + slot_base * (1u + p.bin_list);
-    if (d_block_order_dbg != nullptr && p.rows == rows) {   // (the whole band: class-split launches do not use row halves)
-      p.block_order = d_block_order_dbg;
-      p.block_count = dbg_order_n;
-    }
   }
-  // Experiment hook (rt_dbg_set_block_order, tools/block_order_experiment.py): the order in which a small-scene launch visits
-  // its trace blocks.  Grouping the blocks of certain-winner tiles apart from those that generate rays measured 60.8 -> 57.5 us
-  // per C3 step before the certain-winner path had its table (2.4 % after); a device-side ordering pass behind every list
-  // build cost more than that on the list stream, so the product launches in grid order.
-  uint32_t* d_block_order_dbg = nullptr;
-  uint32_t dbg_order_n = 0, dbg_order_first = 0, dbg_order_pad = 0;   // entries; entries of the first slice (0: one launch); LDS pad of the second
 
   // Small scenes: the per-triangle table of what a certain-winner pixel accumulates in a launch of `samples` samples
   // (rtk::sure_table_kernel), rebuilt when the sample count or the scene changed.  Built on the stream that orders behind
@@ -1217,7 +1190,6 @@ void rt_tracer_destroy(rt_tracer* t) {                                   // RayT
   if (t->d_tri_b) (void)hipFree(t->d_tri_b);
   if (t->d_tri_color) (void)hipFree(t->d_tri_color);
   if (t->d_sure_table) (void)hipFree(t->d_sure_table);
-  if (t->d_block_order_dbg) (void)hipFree(t->d_block_order_dbg);
   if (t->d_spheres) (void)hipFree(t->d_spheres);
   t->release_buffers();
   if (t->handoff_event) (void)hipEventDestroy(t->handoff_event);
@@ -1870,24 +1842,6 @@ int rt_dbg_read_tile_lists(rt_tracer* t, uint32_t* dst, size_t capacity_words, u
     const size_t n = t->tile_lists_words < capacity_words ? t->tile_lists_words : capacity_words;
     HIP_CHECK(hipMemcpy(dst, t->tile_lists_now(), n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (words_per_tile) *words_per_tile = 1u + t->list_key.bin_list;
-  });
-}
-
-int rt_dbg_set_block_order(rt_tracer* t, const uint32_t* order, uint32_t n, uint32_t n_first, uint32_t lds_pad_second) {
-  if (!t || t->mg) return RT_ERR_INVALID;
-  std::lock_guard<std::mutex> lk(t->api_mu);
-  return guarded(t, [&] {
-    t->cancel_and_join();
-    t->use_device();
-    HIP_CHECK(hipStreamSynchronize(t->main_stream()));
-    t->sync_list_stream();
-    if (t->d_block_order_dbg) { HIP_CHECK(hipFree(t->d_block_order_dbg)); t->d_block_order_dbg = nullptr; }
-    if (order == nullptr || n == 0u) return;
-    const uint32_t nb = ((t->W + 31u) / 32u) * ((t->rows + 7u) / 8u);
-    if (n != nb || n_first > n) throw HipFail{"block order: expected one entry per trace block of the band"};
-    HIP_CHECK(hipMalloc(&t->d_block_order_dbg, static_cast<size_t>(n) * sizeof(uint32_t)));
-    HIP_CHECK(hipMemcpy(t->d_block_order_dbg, order, static_cast<size_t>(n) * sizeof(uint32_t), hipMemcpyHostToDevice));
-    t->dbg_order_n = n; t->dbg_order_first = n_first; t->dbg_order_pad = lds_pad_second;
   });
 }
 
