@@ -397,3 +397,12 @@ print(zlib.crc32(g.RenderBuffer().tobytes()), zlib.crc32(g.RngStates().tobytes()
         for _ in range(40): o.trace(1, 2)
         o.rotate_camera((0.45 if k % 2 == 0 else -0.45, 0.0))
     assert outs[""] == "%d %d %d" % (zlib.crc32(o.render.tobytes()), zlib.crc32(o.rng.tobytes()), zlib.crc32(o.image.tobytes()))
+
+
+def test_soak_of_the_split_launch_machinery():
+    """tools/soak_split.py, short: random enqueues, launches, Traces, camera swings, list reuse toggles, scene swaps and Resizes
+    at split-launch sizes with launches in flight, every phase bit-identical to the oracle on sampled rows."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_split.py"), "40", "21"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "bit-identical" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
