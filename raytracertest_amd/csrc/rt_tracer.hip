@@ -463,7 +463,8 @@ struct rt_tracer {
         if (h == 1 && stagger) {
           // half a kernel behind the upper half: by the clock when the tracer knows how long its half-frame kernels take
           // (0.45 of the last sampled one), else behind the upper half's end
-          const uint32_t us = stagger_by_delay ? static_cast<uint32_t>(last_half_ms.load() * 450.0f) : 0u;
+          static const float frac = [] { const char* e = getenv("RT_MI355X_STAGGER_PCT"); const long v = e ? strtol(e, nullptr, 10) : 45; return (v >= 5 && v <= 95 ? v : 45) * 10.0f; }();   // (A/B)
+          const uint32_t us = stagger_by_delay ? static_cast<uint32_t>(last_half_ms.load() * frac) : 0u;
           if (us >= 5u) HIP_CHECK(rtk::launch_delay(us, stream_b));
           else HIP_CHECK(hipStreamWaitEvent(stream_b, stagger_event, 0));
         }
