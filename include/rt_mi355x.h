@@ -149,6 +149,10 @@ int  rt_tracer_upload_spheres(rt_tracer* t, const rt_float4* spheres, size_t cou
  * enqueue clear + iterationCount trace launches + conversion on the tracer's stream, no
  * callbacks, no host synchronisation.  rt_tracer_sync waits for the stream. */
 int  rt_tracer_trace_enqueue(rt_tracer* t, uint32_t iterationCount, uint32_t samplesPerIteration);
+/* n_steps consecutive passes of rt_tracer_trace_enqueue, enqueued by one call (the host loop of a throughput
+ * driver runs inside the library: one lock, no per-step crossing of a foreign-function boundary).  Identical to
+ * n_steps calls of rt_tracer_trace_enqueue. */
+int  rt_tracer_trace_enqueue_n(rt_tracer* t, uint32_t iterationCount, uint32_t samplesPerIteration, uint32_t n_steps);
 int  rt_tracer_sync(rt_tracer* t);
 /* One iteration of TraceFunct's loop as a building block for external drivers (the
  * multi-GPU progressive path, raytracertest_amd/dist.py): enqueue ONE trace launch of

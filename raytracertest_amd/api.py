@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "rt_tracer_stop", "rt_tracer_resize", "rt_tracer_set_camera_parameters",
     "rt_tracer_rotate_camera", "rt_tracer_upload_scene", "rt_tracer_set_update_callback",
     "rt_tracer_set_finished_callback", "rt_tracer_wait", "rt_tracer_set_seed",
-    "rt_tracer_upload_spheres", "rt_tracer_trace_enqueue", "rt_tracer_sync", "rt_tracer_trace_stats", "rt_tracer_launch", "rt_tracer_launch_iterations", "rt_tracer_fused_iterations", "rt_tracer_set_image_mirror", "rt_tracer_set_list_reuse", "rt_tracer_stream_b", "rt_tracer_upload_scene_edges", "rt_pack_normal",
+    "rt_tracer_upload_spheres", "rt_tracer_trace_enqueue", "rt_tracer_trace_enqueue_n", "rt_tracer_sync", "rt_tracer_trace_stats", "rt_tracer_launch", "rt_tracer_launch_iterations", "rt_tracer_fused_iterations", "rt_tracer_set_image_mirror", "rt_tracer_set_list_reuse", "rt_tracer_stream_b", "rt_tracer_upload_scene_edges", "rt_pack_normal",
     "rt_unpack_normal",
     "rt_tracer_kernel_time", "rt_tracer_launch_time", "rt_tracer_read_buffer", "rt_tracer_copy_buffer_to_device", "rt_tracer_copy_buffer_to_device_async",
     "rt_tracer_stream",
@@ -136,6 +136,7 @@ def load_library():
         L.rt_tracer_set_seed.argtypes = [vp, C.c_uint64]
         L.rt_tracer_upload_spheres.argtypes = [vp, vp, C.c_size_t]
         L.rt_tracer_trace_enqueue.argtypes = [vp, C.c_uint32, C.c_uint32]
+        L.rt_tracer_trace_enqueue_n.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32]
         L.rt_tracer_sync.argtypes = [vp]
         L.rt_tracer_launch.argtypes = [vp, C.c_uint32, C.c_int, C.c_int]
         L.rt_tracer_launch_iterations.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
@@ -330,6 +331,10 @@ class RayTracer:
 
     def TraceEnqueue(self, iterationCount, samplesPerIteration):
         self._check(self._lib.rt_tracer_trace_enqueue(self._h, iterationCount, samplesPerIteration))
+
+    def TraceEnqueueN(self, iterationCount, samplesPerIteration, n_steps):
+        """n_steps passes of TraceEnqueue enqueued by one call (the step loop runs inside the library)."""
+        self._check(self._lib.rt_tracer_trace_enqueue_n(self._h, iterationCount, samplesPerIteration, n_steps))
 
     def Launch(self, samples, clear_first=False, emit_image=False, iterations=1):
         """`iterations` iterations of TraceFunct's loop on the device as one launch (no callbacks, no

@@ -8,7 +8,7 @@ LIB = os.path.join(HERE, "lib", "librt_mi355x.so")
 
 
 def build(force=False, verbose=False):
-    cmd = ["make", "-C", CSRC, "all", "cli"]
+    cmd = ["make", "-C", CSRC, "all", "cli", "e2e"]
     if force:
         cmd.append("-B")
     out = None if verbose else subprocess.DEVNULL

@@ -301,11 +301,15 @@ hipError_t launch_prep_triangles(bool fma, bool edges, const float4* verts, uint
   return hipGetLastError();
 }
 
+// small-scene kernels (BIN && ONEPASS): a block of four tiles is 4 / RT_SMALL_WG_WAVES workgroups (trace_kernel)
+constexpr uint32_t kSmallWgWaves = RT_SMALL_WG_WAVES;
+static_assert(kSmallWgWaves == 1u || kSmallWgWaves == 2u || kSmallWgWaves == 4u, "waves per small-scene workgroup");
+
 uint32_t trace_lds_bytes(const TraceParams& p, bool bin) {
   if (bin) {
     const bool large = p.n_tris > p.bin_list;
     const uint32_t per_candidate = (large && (p.flags & TRACE_PRETEST)) ? 104u : 40u;
-    return 4u * p.bin_list * per_candidate + (large ? p.block_list * 4u + 160u : 0u);
+    return (large ? 4u : kSmallWgWaves) * p.bin_list * per_candidate + (large ? p.block_list * 4u + 160u : 0u);
   }
   const uint32_t staged = p.n_tris < p.chunk ? p.n_tris : p.chunk;
   return staged * 36u;
@@ -313,10 +317,12 @@ uint32_t trace_lds_bytes(const TraceParams& p, bool bin) {
 
 template <bool FMA, bool FILTER, bool STATS, bool BIN, bool ONEPASS>
 static void launch_trace_o(const TraceParams& p, int K, dim3 grid, size_t lds, hipStream_t st) {
+  dim3 blk(256);
+  if (BIN && ONEPASS) { grid.x *= 4u / kSmallWgWaves; blk.x = 64u * kSmallWgWaves; }
   switch (K) {
-    case 1: hipLaunchKernelGGL((trace_kernel<FMA, 1, FILTER, STATS, BIN, ONEPASS>), grid, dim3(256), lds, st, p); break;
-    case 2: hipLaunchKernelGGL((trace_kernel<FMA, 2, FILTER, STATS, BIN, ONEPASS>), grid, dim3(256), lds, st, p); break;
-    default: hipLaunchKernelGGL((trace_kernel<FMA, 4, FILTER, STATS, BIN, ONEPASS>), grid, dim3(256), lds, st, p); break;
+    case 1: hipLaunchKernelGGL((trace_kernel<FMA, 1, FILTER, STATS, BIN, ONEPASS>), grid, blk, lds, st, p); break;
+    case 2: hipLaunchKernelGGL((trace_kernel<FMA, 2, FILTER, STATS, BIN, ONEPASS>), grid, blk, lds, st, p); break;
+    default: hipLaunchKernelGGL((trace_kernel<FMA, 4, FILTER, STATS, BIN, ONEPASS>), grid, blk, lds, st, p); break;
   }
 }
 
@@ -351,7 +357,9 @@ template <bool FMA>
 static void launch_trace_fused(const TraceParams& p, int K, dim3 grid, size_t lds, hipStream_t st) {
   const bool onepass = p.n_tris <= p.bin_list;
   if (!onepass && (p.flags & TRACE_PRETEST)) { launch_trace_pre<FMA, false, true>(p, K, grid, lds, st); return; }
-#define RT_FUSED(KK, OP) hipLaunchKernelGGL((trace_kernel<FMA, KK, true, false, true, OP, true>), grid, dim3(256), lds, st, p)
+#define RT_FUSED(KK, OP) hipLaunchKernelGGL((trace_kernel<FMA, KK, true, false, true, OP, true>), grid, blk, lds, st, p)
+  dim3 blk(256);
+  if (onepass) { grid.x *= 4u / kSmallWgWaves; blk.x = 64u * kSmallWgWaves; }
   if (onepass) { if (K == 1) RT_FUSED(1, true); else if (K == 2) RT_FUSED(2, true); else RT_FUSED(4, true); }
   else { if (K == 1) RT_FUSED(1, false); else if (K == 2) RT_FUSED(2, false); else RT_FUSED(4, false); }
 #undef RT_FUSED
@@ -397,8 +405,8 @@ hipError_t launch_trace(const TraceParams& p, bool fma, bool filter, bool bin, i
 int trace_occupancy(int K, size_t lds) {
   int n = 0;
   hipError_t e;
-  if (K == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<true, 1, true, false, true, true>, 256, lds);
-  else if (K == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<true, 2, true, false, true, true>, 256, lds);
+  if (K == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<true, 1, true, false, true, true>, 64 * kSmallWgWaves, lds);
+  else if (K == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<true, 2, true, false, true, true>, 64 * kSmallWgWaves, lds);
   else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<true, 4, true, false, true, false>, 256, lds);
   return e == hipSuccess ? n : -1;
 }
@@ -479,8 +487,7 @@ hipError_t launch_sure_table(const float4* colors, uint32_t n_tris, uint32_t sam
 
 hipError_t launch_tile_lists(const TraceParams& p, bool fma, hipStream_t st) {
   if (p.tile_lists == nullptr || p.rows == 0u || p.W == 0u) return hipSuccess;
-  static const bool flat = [] { const char* e = getenv("RT_MI355X_LISTS_FLAT"); return e && e[0] == '1'; }();   // A/B: one-level build
-  if (p.tile_curv > 0.0f && !flat && p.n_tris <= 256u) {             // two levels: region -> tiles (its LDS candidate list holds 256)
+  if (p.tile_curv > 0.0f && p.n_tris <= 256u) {             // two levels: region -> tiles (its LDS candidate list holds 256)
     const dim3 grid(cdiv(cdiv(p.W, 32) * cdiv(cdiv(p.rows, 8), 2), 4u));
     if (fma) hipLaunchKernelGGL((region_lists_kernel<true>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((region_lists_kernel<false>), grid, dim3(256), 0, st, p);

@@ -258,8 +258,7 @@ int multi_create(const uint32_t imageSize[2], const float cameraPosition[3], con
       g.local.push_back(r);
     }
     // transport: peer stores into the root's frame when asked for and every device may map the root's memory
-    const char* tenv = getenv("RT_MI355X_TRANSPORT");
-    const bool want_peer = (opt.transport == RT_TRANSPORT_PEER || (tenv && strcmp(tenv, "peer") == 0)) && !(tenv && strcmp(tenv, "rccl") == 0);
+    const bool want_peer = opt.transport == RT_TRANSPORT_PEER;
     if (want_peer && !g.self_rccl) {
       g.peer = true;
       for (size_t d = 1; d < m->devices.size() && g.peer; ++d) {

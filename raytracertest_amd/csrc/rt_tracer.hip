@@ -8,6 +8,8 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -29,10 +31,35 @@ namespace {
 std::mutex g_err_mu;
 std::string g_last_error;
 
+// The environment switches of the library, read ONCE per process: every one of them is exercised by
+// a test (tests/test_gpu_*.py) -- A/B knobs of past rounds are gone, their measurements are in HISTORY.md.
+struct Env {
+  bool log;             // RT_MI355X_LOG=1: recorded failures and launch-shape changes go to stderr
+  bool no_split;        // RT_MI355X_NO_SPLIT=1: launches as one kernel on one stream
+  bool no_pretest;      // RT_MI355X_NO_PRETEST=1: no per-sample forms in the dense-scene kernels
+  bool no_sure_table;   // RT_MI355X_NO_SURE_TABLE=1: certain-winner tiles add their samples' colours per pixel
+  int row_interleave;   // RT_MI355X_ROW_INTERLEAVE=0|1: pins the halves of a split small-scene launch (-1: by the builder's counts)
+  long macro_cap;       // RT_MI355X_MACRO_CAP=n: capacity of the macro lists (tests: forces the overflow fallback); 0 = default
+  static bool on(const char* name) { const char* e = getenv(name); return e && e[0] == '1'; }
+  Env() {
+    log = getenv("RT_MI355X_LOG") != nullptr;
+    no_split = on("RT_MI355X_NO_SPLIT");
+    no_pretest = on("RT_MI355X_NO_PRETEST");
+    no_sure_table = on("RT_MI355X_NO_SURE_TABLE");
+    const char* ri = getenv("RT_MI355X_ROW_INTERLEAVE");
+    row_interleave = (ri && (ri[0] == '0' || ri[0] == '1') && ri[1] == 0) ? ri[0] - '0' : -1;
+    const char* mc = getenv("RT_MI355X_MACRO_CAP");
+    macro_cap = mc ? strtol(mc, nullptr, 10) : 0;
+  }
+};
+// (tests flip switches between tracers of one process: the snapshot is taken per tracer, at rt_tracer_create)
+inline Env read_env() { return Env(); }
+
 void set_global_error(const std::string& s) {
   std::lock_guard<std::mutex> lk(g_err_mu);
   g_last_error = s;
-  if (getenv("RT_MI355X_LOG")) fprintf(stderr, "[rt_mi355x] %s\n", s.c_str());
+  static const bool log = getenv("RT_MI355X_LOG") != nullptr;
+  if (log) fprintf(stderr, "[rt_mi355x] %s\n", s.c_str());
 }
 
 std::string fmt(const char* f, ...) {
@@ -115,6 +142,81 @@ struct Camera {
 
 struct EventPair { hipEvent_t a, b, c; uint32_t launches; bool split; uint64_t seq; };   // c: end of the lower half on stream_b
 
+// The render thread of a tracer.  The reference starts a std::thread per Trace and joins the previous one first
+// (RayTracerImpl.cu:69-87); its only caller re-traces on every mouse-move event (OpenGLView/MainFrame.cpp:394-444), so the
+// thread's start-up is part of every frame's latency.  Here ONE thread per tracer, created by the first Trace, runs the
+// Traces one after the other: between two of them it polls for the next job for a short while (a drag loop's next Trace
+// arrives within microseconds of the finished callback) and then parks on a condition variable.  What a caller can observe
+// is unchanged: run() returns at once, the job and its callbacks run on a thread that is not the caller's, wait_idle() is
+// the join.
+class RenderThread {
+ public:
+  ~RenderThread() { shutdown(); }
+  bool busy() const { return busy_.load(std::memory_order_acquire); }
+  // hands `job` to the render thread; the previous job has finished (callers cancel + wait_idle() first)
+  void run(std::function<void()> job) {
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [&] { return !busy_.load(); });
+    if (!th_.joinable()) th_ = std::thread([this] { loop(); });
+    job_ = std::move(job);
+    busy_.store(true, std::memory_order_release);
+    posted_.store(true, std::memory_order_release);
+    lk.unlock();
+    cv_.notify_one();
+  }
+  void wait_idle() {
+    if (!busy()) return;
+    for (int i = 0; i < 2000 && busy(); ++i) spin_pause();              // a short Trace ends within microseconds
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [&] { return !busy_.load(); });
+  }
+  void shutdown() {
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      done_cv_.wait(lk, [&] { return !busy_.load(); });
+      quit_ = true;
+    }
+    cv_.notify_one();
+    if (th_.joinable()) th_.join();
+  }
+
+ private:
+  static void spin_pause() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+  }
+  void loop() {
+    for (;;) {
+      // poll ~50 us for the next job before parking (no lock taken while polling)
+      const auto t0 = std::chrono::steady_clock::now();
+      while (!posted_.load(std::memory_order_acquire) &&
+             std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(50)) spin_pause();
+      std::function<void()> job;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return posted_.load() || quit_; });
+        if (!posted_.load()) return;                                   // quit
+        posted_.store(false);
+        job = std::move(job_);
+        job_ = nullptr;
+      }
+      job();
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        busy_.store(false, std::memory_order_release);
+      }
+      done_cv_.notify_all();
+    }
+  }
+  std::thread th_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_cv_;
+  std::function<void()> job_;
+  std::atomic<bool> busy_{false}, posted_{false};
+  bool quit_ = false;
+};
+
 struct Group;        // rt_multi.hpp: the tile gather of a frame sharded over several GPUs
 struct MultiState;   // rt_multi.hpp: the bands of a multi-device tracer
 
@@ -128,6 +230,7 @@ struct rt_tracer {
   Group* grp = nullptr;
   MultiState* mg = nullptr;
   // configuration
+  Env env;                          // the environment switches as they were at rt_tracer_create
   int device = 0;
   uint32_t W = 0, H = 0;            // full image
   uint32_t row0 = 0, rows = 0;      // owned band
@@ -196,7 +299,7 @@ struct rt_tracer {
 
   // render thread
   std::mutex api_mu;
-  std::thread thread;
+  RenderThread render;
   std::atomic<bool> stopped{false};
   std::atomic<bool> completed{false};
 
@@ -221,9 +324,9 @@ struct rt_tracer {
   void use_device() { HIP_CHECK(hipSetDevice(device)); }
 
   void cancel_and_join() {                                               // RayTracerImpl.cu:72-77
-    if (thread.joinable()) {
+    if (render.busy()) {
       stopped = true;
-      thread.join();
+      render.wait_idle();
       stopped = false;
     }
   }
@@ -351,8 +454,7 @@ struct rt_tracer {
     p.bin_list = want < 32u ? 32u : want > (bin_list_req ? 960u : 256u) ? (bin_list_req ? 960u : 256u) : want;
     // scenes that do not fit the per-wave list: 192 records per wave + a 1024-entry block-level
     // pre-cull list keep the block at 34.9 KiB of LDS (4 blocks per CU)
-    const char* nb = getenv("RT_MI355X_NO_BLOCK_LIST");
-    p.block_list = (n_tris > p.bin_list && !(nb && nb[0] == '1')) ? 1024u : 0u;
+    p.block_list = n_tris > p.bin_list ? 1024u : 0u;
     if (p.block_list != 0u && !bin_list_req) p.bin_list = 192u;
     // Per-sample conservative forms (TRACE_PRETEST) for the large-scene kernels: 76 instead of 40 bytes per
     // candidate in LDS, so 128 candidates per wave and a 448-entry block list keep the block at 40 KiB
@@ -416,7 +518,7 @@ struct rt_tracer {
     // 5.6 us per C3 step (157.9 -> 152.3 us) and 2.3x on the 38x21 interactive loop (13.9 -> 6.0 us
     // per iteration) with both events on every launch.  The mean of the sampled launches is what
     // rt_tracer_kernel_time reports; the first launch after a reset is always sampled.
-    const bool timed = sync_after == 1 || event_stride <= 1u || (launch_counter++ % event_stride) == 0u;
+    const bool timed = sync_after == 1 || (launch_counter++ % kEventStride) == 0u;
     // Tall frames: upper half on the primary stream, lower half on stream_b (see the fields' comment).
     // The split row is a multiple of 8, each half is a row band of its own (own tile / macro lists).
     const uint32_t r0 = allow_split ? split_row(p.rows) : 0u;
@@ -424,47 +526,42 @@ struct rt_tracer {
     if (timed) { e = take_events(); e.launches = 1; e.split = r0 != 0u; }
     if (r0 == 0u) {
       (void)main_stream();                                               // a launch on one stream orders behind both
-      if (build_lists && !lists_inline) build_tile_lists_ahead(p);
+      if (build_lists) build_tile_lists_ahead(p);
       attach_tile_lists(p, have_lists);
       if (timed) HIP_CHECK(hipEventRecord(e.a, stream));
-      if (build_lists && lists_inline) HIP_CHECK(rtk::launch_tile_lists(p, fma, stream));   // part of the launch: timed with it
       if (have_lists) wait_for_lists(stream, list_waited_a);
       attach_macro_lists(p, 0, stream, (flags & rtk::TRACE_ZERO_ACC) != 0u);   // part of the launch: timed with it
       HIP_CHECK(rtk::launch_trace(p, fma, filter, bin, K, stream));
       if (timed) HIP_CHECK(hipEventRecord(e.b, stream));
     } else {
       fork_b();
-      if (build_lists && !lists_inline) build_tile_lists_ahead(p);
+      if (build_lists) build_tile_lists_ahead(p);
       // The two halves overlap best in ANTI-phase (one half's drain under the other's bulk); started together -- both
       // released by the same event, or from an idle device -- they can lock IN phase and stay there for a whole run
       // (measured at C3: 93 instead of 80 us per step, profiles/r03_phase_regimes.txt).  The first split launch after
       // the tracer was idle therefore lets its second kernel start about half a kernel behind its first (a delay wave, or
       // -- before any kernel has been sampled -- behind the first kernel's end).  Later launches free-run.
-      const bool stagger = stagger_next.exchange(false) && !no_stagger;
+      const bool stagger = stagger_next.exchange(false);
       // Small scenes: the halves are the band's upper and lower rows or its even and odd block rows (want_interleave()).
       // Dense scenes keep row halves (their macro lists are per half, in macro tiles of 8 block rows).
-      const bool interleave = have_lists && !lists_inline && want_interleave();
+      const bool interleave = have_lists && want_interleave();
       if (have_lists && interleave != rows_interleaved) {                  // pixels change streams: everything before goes first
         (void)main_stream();
         fork_b();
         rows_interleaved = interleave;
-        static const bool log = getenv("RT_MI355X_LOG") != nullptr;
-        if (log) fprintf(stderr, "[rt_mi355x] split launches: halves by %s\n", interleave ? "even / odd block rows" : "rows");
+        if (env.log) fprintf(stderr, "[rt_mi355x] split launches: halves by %s\n", interleave ? "even / odd block rows" : "rows");
       }
       rtk::TraceParams half[2] = {sub_band(p, 0u, r0), sub_band(p, r0, p.rows - r0)};
-      static const uint32_t il_group = [] { const char* e = getenv("RT_MI355X_ROW_GROUP"); const long v = e ? strtol(e, nullptr, 10) : 1; return static_cast<uint32_t>(v >= 1 && v <= 64 ? v : 1); }();
-      if (interleave) { half[0] = p; half[1] = p; half[0].row_il = half[1].row_il = il_group; half[1].row_phase = 1u; }
+      if (interleave) { half[0] = p; half[1] = p; half[0].row_il = half[1].row_il = 1u; half[1].row_phase = 1u; }
       hipStream_t st[2] = {stream, stream_b};
       if (timed) HIP_CHECK(hipEventRecord(e.a, stream));                 // the sampled duration is the upper half-frame kernel's
       for (int h = 0; h < 2; ++h) {
         attach_tile_lists(half[h], have_lists);
-        if (build_lists && lists_inline) HIP_CHECK(rtk::launch_tile_lists(half[h], fma, st[h]));   // each half builds the lists of its own rows
         if (have_lists) wait_for_lists(st[h], h == 0 ? list_waited_a : list_waited_b);
         if (h == 1 && stagger) {
           // half a kernel behind the upper half: by the clock when the tracer knows how long its half-frame kernels take
           // (0.45 of the last sampled one), else behind the upper half's end
-          static const float frac = [] { const char* e = getenv("RT_MI355X_STAGGER_PCT"); const long v = e ? strtol(e, nullptr, 10) : 45; return (v >= 5 && v <= 95 ? v : 45) * 10.0f; }();   // (A/B)
-          const uint32_t us = stagger_by_delay ? static_cast<uint32_t>(last_half_ms.load() * frac) : 0u;
+          const uint32_t us = static_cast<uint32_t>(last_half_ms.load() * 450.0f);
           if (us >= 5u) HIP_CHECK(rtk::launch_delay(us, stream_b));
           else HIP_CHECK(hipStreamWaitEvent(stream_b, stagger_event, 0));
         }
@@ -488,7 +585,7 @@ struct rt_tracer {
       pending.push_back(e);
       // flow control in units of sampled launches: with stride s the launch waited for is
       // max(s, sync_after) launches back, i.e. fewer than sync_after + s launches are in flight
-      const size_t stride = event_stride > 1u ? event_stride : 1u;
+      const size_t stride = kEventStride;
       back = (static_cast<size_t>(sync_after > 1 ? sync_after : 2) + stride - 1u) / stride;
       if (back < 2u) back = 2u;
       if (sync_after == 1) { waited = e; wait_for = &waited; }
@@ -561,6 +658,20 @@ struct rt_tracer {
     HIP_CHECK(rtk::launch_convert(d_render, d_counts, d_image, npix(), main_stream()));
   }
 
+  // Waits for a stream with the host polling: the end of a Trace is latency, not throughput (the reference's caller re-traces
+  // on every mouse-move event), and the runtime's blocking wait adds its wake-up to every frame.  Long waits block.
+  static void sync_polling(hipStream_t st) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      const hipError_t e = hipStreamQuery(st);
+      if (e == hipSuccess) return;
+      if (e != hipErrorNotReady) HIP_CHECK(e);
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+    (void)hipGetLastError();                                             // hipErrorNotReady is an answer, not a failure
+    HIP_CHECK(hipStreamSynchronize(st));
+  }
+
   void fetch_image() {                                                   // device image -> pinned host copy
     HIP_CHECK(hipMemcpyAsync(h_image, d_image, static_cast<size_t>(npix()) * sizeof(uint32_t),
                              hipMemcpyDeviceToHost, main_stream()));
@@ -588,10 +699,8 @@ struct rt_tracer {
   // kernel enqueued before it -- and the ring is long enough that a build always finds such an event that is at least
   // kFreeStride builds old and still covers the readers of the slot it overwrites (build m: the oldest recorded at a build
   // e >= m - kListRing + 1; then m - kListRing < e <= m - kFreeStride).
-  // RT_MI355X_LISTS_INLINE=1: build on the trace streams, one slot (A/B).
   static constexpr int kListRing = 8, kFreeEvents = 10;
-  int ring_n = 8, kFreeStride = 4;    // RT_MI355X_LIST_RING=slots:stride (A/B; stride <= slots - 2, or 1)
-  bool ring_from_env = false;
+  int ring_n = 8, kFreeStride = 4;    // (4 : 2 when one slot exceeds 128 MiB; measured alternatives: HISTORY.md "List ring")
   uint32_t* d_list_ring[kListRing] = {};
   hipEvent_t list_ready[kListRing] = {};
   hipEvent_t list_free_a[kFreeEvents] = {}, list_free_b[kFreeEvents] = {};
@@ -601,11 +710,8 @@ struct rt_tracer {
   uint64_t list_builds = 0;           // builds so far; the trace streams remember which one they have waited for
   uint64_t list_waited_a = 0, list_waited_b = 0;
   hipStream_t stream_l = nullptr;
-  bool lists_inline = false;
   std::atomic<bool> stagger_next{true};   // the next split launch starts from an idle tracer: stagger its halves (enqueue_trace_launch)
   hipEvent_t stagger_event = nullptr;
-  bool no_stagger = false;                // RT_MI355X_NO_STAGGER=1 (A/B)
-  bool stagger_by_delay = true;           // RT_MI355X_STAGGER_EVENT=1: always behind the upper half's end (A/B)
   std::atomic<float> last_half_ms{0.0f};  // duration of the last sampled upper half-frame kernel of a split launch
   size_t tile_lists_words = 0;
   uint32_t* tile_lists_now() const { return d_list_ring[list_cur]; }
@@ -618,9 +724,8 @@ struct rt_tracer {
   uint32_t* d_half_cost = nullptr;                // two device counters
   unsigned long long* h_half_cost = nullptr;      // pinned: upper | lower << 32 of the latest finished build
   bool rows_interleaved = false;
-  int interleave_mode = -1;                       // RT_MI355X_ROW_INTERLEAVE=0/1 pins it (A/B); -1: by the counts
   bool want_interleave() {
-    if (interleave_mode >= 0) return interleave_mode != 0;
+    if (env.row_interleave >= 0) return env.row_interleave != 0;
     if (h_half_cost == nullptr) return false;
     const unsigned long long w = *reinterpret_cast<volatile unsigned long long*>(h_half_cost);
     const double u = static_cast<double>(w & 0xFFFFFFFFull), l = static_cast<double>(w >> 32);
@@ -629,8 +734,7 @@ struct rt_tracer {
     return rows_interleaved ? ratio > 1.15 : ratio > 1.25;
   }
   uint32_t split_row(uint32_t band_rows) const {   // first row of the lower half of a split launch (a multiple of 8); 0 = not split
-    static const uint32_t split_pct = [] { const char* e = getenv("RT_MI355X_SPLIT_PCT"); const long v = e ? strtol(e, nullptr, 10) : 50; return static_cast<uint32_t>(v >= 10 && v <= 90 ? v : 50); }();
-    return (split_launches && band_rows >= 128u) ? ((band_rows * split_pct / 100u + 7u) / 8u) * 8u : 0u;
+    return (split_launches && band_rows >= 128u) ? ((band_rows / 2u + 7u) / 8u) * 8u : 0u;   // (40 / 45 / 55 / 60 % measured: the halves have to cost the same)
   }
   void release_tile_lists() {         // callers have synchronised every stream
     for (int r = 0; r < kListRing; ++r) { if (d_list_ring[r]) (void)hipFree(d_list_ring[r]); d_list_ring[r] = nullptr; }
@@ -656,15 +760,15 @@ struct rt_tracer {
       HIP_CHECK(hipStreamSynchronize(main_stream()));
       sync_list_stream();
       release_tile_lists();
-      if (!ring_from_env) {                                              // long lists on large frames: a shorter ring (<= 1 GiB of lists)
+      {                                                                  // long lists on large frames: a shorter ring (<= 1 GiB of lists)
         const bool big = words * sizeof(uint32_t) > (size_t(128) << 20);
         ring_n = big ? 4 : 8; kFreeStride = big ? 2 : 4;
       }
-      for (int r = 0; r < (lists_inline ? 1 : ring_n); ++r) {
+      for (int r = 0; r < ring_n; ++r) {
         HIP_CHECK(hipMalloc(&d_list_ring[r], words * sizeof(uint32_t)));
         // count 0 everywhere until a launch builds; on the stream the builds run on (a hipMemset on the null stream is not
         // ordered with the non-blocking streams and may land AFTER the first build)
-        HIP_CHECK(hipMemsetAsync(d_list_ring[r], 0, words * sizeof(uint32_t), lists_inline ? stream : stream_l));
+        HIP_CHECK(hipMemsetAsync(d_list_ring[r], 0, words * sizeof(uint32_t), stream_l));
       }
       tile_lists_words = words;
     }
@@ -674,9 +778,7 @@ struct rt_tracer {
     k.half_height = p.half_height; k.aspect = p.aspect; k.focal = p.focal; k.aperture = p.aperture;
     k.W = p.W; k.H = p.H; k.row0 = p.row0; k.rows = p.rows; k.bin_list = p.bin_list; k.n_tris = p.n_tris;
     k.scene_generation = scene_generation; k.fma = fma;
-    static const bool never = [] { const char* e = getenv("RT_MI355X_NO_LIST_REUSE"); return e && e[0] == '1'; }();   // A/B: every launch builds
-    const bool same = list_key_valid && memcmp(&k, &list_key, sizeof k) == 0 && !never &&
-                      !(first_launch_of_trace && !reuse_across_traces);
+    const bool same = list_key_valid && memcmp(&k, &list_key, sizeof k) == 0 && !(first_launch_of_trace && !reuse_across_traces);
     if (same) return false;
     list_key = k;
     list_key_valid = true;
@@ -700,8 +802,7 @@ struct rt_tracer {
   uint64_t sure_table_scene = ~0ull;
   void attach_sure_table(rtk::TraceParams& p, bool have) {
     p.sure_table = nullptr;
-    static const bool off = [] { const char* e = getenv("RT_MI355X_NO_SURE_TABLE"); return e && e[0] == '1'; }();
-    if (!have || off || p.n_tris == 0u) return;
+    if (!have || env.no_sure_table || p.n_tris == 0u) return;
     if (sure_table_samples != p.samples || sure_table_scene != scene_generation || sure_table_cap < p.n_tris) {
       hipStream_t st = main_stream();
       if (sure_table_cap < p.n_tris) {
@@ -739,7 +840,7 @@ struct rt_tracer {
     const uint32_t sr = split_row(rows);
     // (counted by every 32nd build only: the atomics and the publishing kernel cost 3.5 us per step when every build has
     //  them -- and nothing to decide when the mode is pinned)
-    if (sr != 0u && d_half_cost != nullptr && interleave_mode < 0 && (m % 32u) == 0u) { q.half_cost = d_half_cost; q.cost_split_brow = sr / 8u; }
+    if (sr != 0u && d_half_cost != nullptr && env.row_interleave < 0 && (m % 32u) == 0u) { q.half_cost = d_half_cost; q.cost_split_brow = sr / 8u; }
     HIP_CHECK(rtk::launch_tile_lists(q, fma, stream_l));
     HIP_CHECK(hipEventRecord(list_ready[r], stream_l));
     if (q.half_cost != nullptr) HIP_CHECK(rtk::launch_publish_half_cost(d_half_cost, h_half_cost, stream_l));   // (behind list_ready: nobody waits for it)
@@ -747,7 +848,7 @@ struct rt_tracer {
   }
   // stream `st` (the primary stream or stream_b) is about to run a trace kernel that reads the current lists
   void wait_for_lists(hipStream_t st, uint64_t& waited) {
-    if (lists_inline || waited == list_builds) return;
+    if (waited == list_builds) return;
     HIP_CHECK(hipStreamWaitEvent(st, list_ready[list_cur], 0));
     waited = list_builds;
   }
@@ -755,13 +856,13 @@ struct rt_tracer {
   // Macro level of the classification (scenes that do not fit the per-wave list): sizes the
   // lists, points the launch at them and runs macro_bin_kernel on the stream ahead of the trace
   // launch.  Every launch re-bins (the camera may have changed; the pass costs N x macro tiles tests).
-  uint32_t event_stride = 4;                      // every 4th launch carries timing events (RT_MI355X_EVENT_STRIDE)
+  static constexpr uint32_t kEventStride = 4;     // every 4th launch carries timing events (an event record is a packet the next kernel queues behind)
   std::atomic<uint32_t> launch_counter{0};
   uint32_t* d_macro_lists[2] = {nullptr, nullptr};   // one per half of a split launch
   size_t macro_lists_words[2] = {0, 0};
-  bool macro = true;                  // RT_FLAG_NO_MACRO_BINS / RT_MI355X_NO_MACRO=1 turn it off
+  bool macro = true;                  // RT_FLAG_NO_MACRO_BINS turns it off
   bool pretest = true;                // RT_MI355X_NO_PRETEST=1 turns the per-sample forms off
-  bool sure_hit = true;               // RT_FLAG_NO_SURE_HIT / RT_MI355X_NO_SUREHIT=1: tiles of one certainly-hit triangle run the tests anyway
+  bool sure_hit = true;               // RT_FLAG_NO_SURE_HIT: tiles of one certainly-hit triangle run the tests anyway
   // Stored tile candidate lists (small scenes) survive from one Trace to the next while camera, lens, scene,
   // frame and arithmetic mode are unchanged -- like any acceleration structure that is rebuilt only when its
   // inputs change.  rt_tracer_set_list_reuse(t, 0) restricts the reuse to the launches of one Trace.
@@ -780,17 +881,10 @@ struct rt_tracer {
     p.macro_lists = nullptr;
     if (!bin || !macro || p.n_tris <= p.bin_list) return;
     p.macro_w = kMacroW; p.macro_h = kMacroH;
-    if (const char* ms = getenv("RT_MI355X_MACRO_TILE")) {              // tuning: "WxH", multiples of 32 x 8
-      unsigned w = 0, h = 0;
-      if (sscanf(ms, "%ux%u", &w, &h) == 2 && w >= 32u && h >= 8u && w % 32u == 0u && h % 8u == 0u) { p.macro_w = w; p.macro_h = h; }
-    }
     p.macro_nx = (p.W + p.macro_w - 1u) / p.macro_w;
     const uint32_t ny = (p.rows + p.macro_h - 1u) / p.macro_h;
     p.macro_cap = p.n_tris < kMacroCapMax ? p.n_tris : kMacroCapMax;
-    if (const char* mc = getenv("RT_MI355X_MACRO_CAP")) {               // tests: force the overflow fallback
-      const long v = strtol(mc, nullptr, 10);
-      if (v > 0 && static_cast<uint32_t>(v) < p.macro_cap) p.macro_cap = static_cast<uint32_t>(v);
-    }
+    if (env.macro_cap > 0 && static_cast<uint32_t>(env.macro_cap) < p.macro_cap) p.macro_cap = static_cast<uint32_t>(env.macro_cap);   // tests: force the overflow fallback
     const size_t words = static_cast<size_t>(p.macro_nx) * ny * (p.macro_cap + 1u);
     if (words > macro_lists_words[half]) {                              // (hipFree waits for the device: safe while the other half runs)
       if (d_macro_lists[half]) (void)hipFree(d_macro_lists[half]);
@@ -805,9 +899,7 @@ struct rt_tracer {
     k.half_height = p.half_height; k.aspect = p.aspect; k.focal = p.focal; k.aperture = p.aperture;
     k.W = p.W; k.H = p.H; k.row0 = p.row0; k.rows = p.rows; k.bin_list = p.macro_cap * 65536u + p.macro_w * 256u + p.macro_h; k.n_tris = p.n_tris;
     k.scene_generation = scene_generation; k.fma = fma;
-    static const bool never = [] { const char* e = getenv("RT_MI355X_NO_LIST_REUSE"); return e && e[0] == '1'; }();
-    const bool same = macro_key_valid[half] && memcmp(&k, &macro_key[half], sizeof k) == 0 && !never &&
-                      !(first_launch_of_trace && !reuse_across_traces);
+    const bool same = macro_key_valid[half] && memcmp(&k, &macro_key[half], sizeof k) == 0 && !(first_launch_of_trace && !reuse_across_traces);
     if (same) return;
     macro_key[half] = k;
     macro_key_valid[half] = true;
@@ -841,8 +933,7 @@ struct rt_tracer {
   // How many consecutive iterations one launch may run (1 = no fusing): bounded so that a launch
   // stays short (<= 64 samples per pixel) and a Stop() takes effect within a few launches.
   uint32_t fused_iterations(uint32_t samplesPerIteration) const {
-    static const bool off = [] { const char* e = getenv("RT_MI355X_NO_FUSE"); return e && e[0] == '1'; }();
-    if (off || !rtk::trace_can_fuse(filter, bin) || samplesPerIteration == 0u) return 1u;
+    if (!rtk::trace_can_fuse(filter, bin) || samplesPerIteration == 0u) return 1u;
     const uint32_t n = 64u / samplesPerIteration;
     return n < 1u ? 1u : n;
   }
@@ -903,7 +994,7 @@ struct rt_tracer {
       }
       if (stopped) { HIP_CHECK(hipStreamSynchronize(main_stream())); return; }   // :280-284, no callback
       if (cleared && i == iterationCount) {
-        HIP_CHECK(hipStreamSynchronize(main_stream()));                         // the last launch wrote final_image itself
+        sync_polling(main_stream());                                     // the last launch wrote final_image itself
       } else {
         fetch_image();                                                   // :287-295 (no launch ran)
         final_image = h_image;
@@ -1066,18 +1157,11 @@ int rt_tracer_create_ex(const uint32_t imageSize[2], const float cameraPosition[
   t->bin = (opt.flags & RT_FLAG_NO_BINNING) == 0;
   t->nearest_hit = (opt.flags & RT_FLAG_NEAREST_HIT) != 0;
   t->smooth_normals = (opt.flags & RT_FLAG_SMOOTH_NORMALS) != 0;
-  { const char* np = getenv("RT_MI355X_NO_PRETEST"); t->pretest = !(np && np[0] == '1'); }
-  { const char* nh = getenv("RT_MI355X_NO_SUREHIT"); t->sure_hit = (opt.flags & RT_FLAG_NO_SURE_HIT) == 0 && !(nh && nh[0] == '1'); }
-  { const char* ns = getenv("RT_MI355X_NO_SPLIT"); t->split_launches = !(ns && ns[0] == '1'); }
-  if (const char* lr = getenv("RT_MI355X_LIST_RING")) {
-    int n = 0, st = 0;
-    if (sscanf(lr, "%d:%d", &n, &st) == 2 && n >= 3 && n <= rt_tracer::kListRing && st >= 1 && (st == 1 || st <= n - 2)) { t->ring_n = n; t->kFreeStride = st; t->ring_from_env = true; }
-  }
-  if (const char* es = getenv("RT_MI355X_EVENT_STRIDE")) t->event_stride = static_cast<uint32_t>(strtoul(es, nullptr, 10));
-  {
-    const char* nm = getenv("RT_MI355X_NO_MACRO");
-    t->macro = (opt.flags & RT_FLAG_NO_MACRO_BINS) == 0 && !(nm && nm[0] == '1');
-  }
+  t->env = read_env();
+  t->pretest = !t->env.no_pretest;
+  t->sure_hit = (opt.flags & RT_FLAG_NO_SURE_HIT) == 0;
+  t->split_launches = !t->env.no_split;
+  t->macro = (opt.flags & RT_FLAG_NO_MACRO_BINS) == 0;
   t->k_req = opt.samples_in_flight;
   t->chunk_req = opt.lds_chunk;
   t->bin_list_req = opt.bin_list;
@@ -1092,36 +1176,20 @@ int rt_tracer_create_ex(const uint32_t imageSize[2], const float cameraPosition[
     HIP_CHECK(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
     // The runtime maps streams onto a few hardware queues.  The two streams of the first tracer of a process get queues
     // of their own; a tracer created while another one is alive on the device was measured 20 % slower (its two
-    // half-frame kernels serialise on one queue; tools/placement_probe.py).  RT_MI355X_STREAM_PRIO=1 creates the second
-    // stream at high priority, which gives such a tracer its concurrency back (172 -> 153 us) but costs the first
-    // tracer 7 % (145 vs 135 us), so it is opt-in; GPU_MAX_HW_QUEUES=8 in the environment cures both.
+    // half-frame kernels serialise on one queue; tools/placement_probe.py); GPU_MAX_HW_QUEUES=8 in the environment cures it.
+    HIP_CHECK(hipStreamCreateWithFlags(&t->stream_b, hipStreamNonBlocking));
     {
-      const char* sp = getenv("RT_MI355X_STREAM_PRIO");
-      int lo = 0, hi = 0;
-      if (sp && sp[0] == '1' && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
-        HIP_CHECK(hipStreamCreateWithPriority(&t->stream_b, hipStreamNonBlocking, hi));
-      else
-        HIP_CHECK(hipStreamCreateWithFlags(&t->stream_b, hipStreamNonBlocking));
-    }
-    {
-      const char* li = getenv("RT_MI355X_LISTS_INLINE");
-      t->lists_inline = li && li[0] == '1';
       int lo = 0, hi = 0;                                                // (numerically lower = higher priority)
-      if (!t->lists_inline) {
-        if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo && !getenv("RT_MI355X_LISTS_NO_PRIO"))
-          HIP_CHECK(hipStreamCreateWithPriority(&t->stream_l, hipStreamNonBlocking, hi));
-        else
-          HIP_CHECK(hipStreamCreateWithFlags(&t->stream_l, hipStreamNonBlocking));
-      }
+      if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
+        HIP_CHECK(hipStreamCreateWithPriority(&t->stream_l, hipStreamNonBlocking, hi));
+      else
+        HIP_CHECK(hipStreamCreateWithFlags(&t->stream_l, hipStreamNonBlocking));
       HIP_CHECK(hipEventCreateWithFlags(&t->stagger_event, hipEventDisableTiming));
       HIP_CHECK(hipMalloc(&t->d_half_cost, 2 * sizeof(uint32_t)));
       HIP_CHECK(hipMemset(t->d_half_cost, 0, 2 * sizeof(uint32_t)));
       HIP_CHECK(hipDeviceSynchronize());                                  // (a null-stream memset is not ordered with the list stream)
       HIP_CHECK(hipHostMalloc(&t->h_half_cost, sizeof(unsigned long long), hipHostMallocDefault));
       *t->h_half_cost = 0ull;
-      if (const char* ri = getenv("RT_MI355X_ROW_INTERLEAVE")) { if ((ri[0] == '0' || ri[0] == '1') && ri[1] == 0) t->interleave_mode = ri[0] - '0'; }
-      { const char* ns2 = getenv("RT_MI355X_NO_STAGGER"); t->no_stagger = ns2 && ns2[0] == '1'; }
-      { const char* se = getenv("RT_MI355X_STAGGER_EVENT"); t->stagger_by_delay = !(se && se[0] == '1'); }
       for (int r = 0; r < rt_tracer::kListRing; ++r) HIP_CHECK(hipEventCreateWithFlags(&t->list_ready[r], hipEventDisableTiming));
       for (int r = 0; r < rt_tracer::kFreeEvents; ++r) {
         HIP_CHECK(hipEventCreateWithFlags(&t->list_free_a[r], hipEventDisableTiming));
@@ -1161,7 +1229,7 @@ int rt_tracer_create(const uint32_t imageSize[2], const float cameraPosition[3],
 void rt_tracer_destroy(rt_tracer* t) {                                   // RayTracerImpl.cu:48-67
   if (!t) return;
   t->stopped = true;
-  if (t->thread.joinable()) t->thread.join();
+  t->render.shutdown();
   if (t->mg) {                                                           // multi-device: the bands own the device state
     multi_destroy(t);
     delete t;
@@ -1208,9 +1276,8 @@ int rt_tracer_trace(rt_tracer* t, uint32_t iterationCount, uint32_t samplesPerIt
   return guarded(t, [&] {
     t->cancel_and_join();                                                // :72-77
     t->completed = false;
-    if (t->mg) t->thread = std::thread(multi_trace_funct, t, iterationCount, samplesPerIteration, updateInterval);
-    else t->thread = std::thread(&rt_tracer::trace_funct, t, iterationCount, samplesPerIteration,
-                                 updateInterval);                        // :80-85
+    if (t->mg) t->render.run([=] { multi_trace_funct(t, iterationCount, samplesPerIteration, updateInterval); });
+    else t->render.run([=] { t->trace_funct(iterationCount, samplesPerIteration, updateInterval); });   // :80-85
   });
 }
 
@@ -1221,7 +1288,7 @@ void rt_tracer_stop(rt_tracer* t) {                                      // :89-
 int rt_tracer_wait(rt_tracer* t) {
   if (!t) return 0;
   std::lock_guard<std::mutex> lk(t->api_mu);
-  if (t->thread.joinable()) t->thread.join();
+  t->render.wait_idle();
   t->stopped = false;
   return t->completed ? 1 : 0;
 }
@@ -1387,21 +1454,35 @@ int rt_tracer_set_seed(rt_tracer* t, uint64_t seed) {
   });
 }
 
+// one device-resident Trace pass on any kind of handle (api_mu held, render thread idle)
+static void trace_enqueue_once(rt_tracer* t, uint32_t iterationCount, uint32_t samplesPerIteration) {
+  if (t->mg) { multi_trace_enqueue(t, iterationCount, samplesPerIteration); return; }
+  if (t->grp) {                                                          // member of a multi-process group: trace, then the gather
+    const size_t k = member_band_index(t);
+    const int b = t->grp->begin_frame();
+    t->trace_enqueue_body(iterationCount, samplesPerIteration, t->grp->tile_target(k, b));
+    t->grp->tile_written(k);
+    t->grp->gather(b);
+    return;
+  }
+  t->trace_enqueue_body(iterationCount, samplesPerIteration, t->image_mirror);
+}
+
 int rt_tracer_trace_enqueue(rt_tracer* t, uint32_t iterationCount, uint32_t samplesPerIteration) {
   if (!t) return RT_ERR_INVALID;
   std::lock_guard<std::mutex> lk(t->api_mu);
   return guarded(t, [&] {
     t->cancel_and_join();
-    if (t->mg) { multi_trace_enqueue(t, iterationCount, samplesPerIteration); return; }
-    if (t->grp) {                                                        // member of a multi-process group: trace, then the gather
-      const size_t k = member_band_index(t);
-      const int b = t->grp->begin_frame();
-      t->trace_enqueue_body(iterationCount, samplesPerIteration, t->grp->tile_target(k, b));
-      t->grp->tile_written(k);
-      t->grp->gather(b);
-      return;
-    }
-    t->trace_enqueue_body(iterationCount, samplesPerIteration, t->image_mirror);
+    trace_enqueue_once(t, iterationCount, samplesPerIteration);
+  });
+}
+
+int rt_tracer_trace_enqueue_n(rt_tracer* t, uint32_t iterationCount, uint32_t samplesPerIteration, uint32_t n_steps) {
+  if (!t) return RT_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(t->api_mu);
+  return guarded(t, [&] {
+    t->cancel_and_join();
+    for (uint32_t s = 0; s < n_steps; ++s) trace_enqueue_once(t, iterationCount, samplesPerIteration);
   });
 }
 

@@ -233,6 +233,16 @@ class RowBandJob:
         if self.exchange is not None:
             self.exchange.after_emit(self)
 
+    def steps(self, n):
+        """n consecutive step()s.  With the library's own exchange (or none) the loop runs inside the library
+        (rt_tracer_trace_enqueue_n): one call, no per-step crossing of ctypes."""
+        if self.exchange is None or isinstance(self.exchange, NativeExchange):
+            if n > 0:
+                self.tracer.TraceEnqueueN(self.cfg["iterations"], self.cfg["samples"], n)
+            return
+        for _ in range(n):
+            self.step()
+
     def finish(self):
         self.tracer.Sync()
 

@@ -72,6 +72,13 @@ FRAMES = {
     # BASELINE configs[4]: the C4 scene at 256 spp (one launch), same four rows of the 3840x2160 frame
     "C5_band4": dict(W=3840, H=2160, row0=1078, rows=4, scene="rand10k", it=1, spp=256, fov=70.0, focal=3.0, aperture=0.05),
 }
+# More rows of the full-size dense-scene frames (the default launch's three-level classification was
+# oracle-checked on rows 1078..1081 only): the frame's first and last rows, the seams of the 128x64 macro tiles, rows
+# spread over the frame -- and for C5 rows inside different 270-row bands of the 8-band partition.
+for _r in (0, 62, 377, 707, 1022, 1533, 1899, 2156):
+    FRAMES["C4_rows%04d" % _r] = dict(W=3840, H=2160, row0=_r, rows=4, scene="rand10k", it=1, spp=64, fov=70.0, focal=3.0, aperture=0.05)
+for _r in (133, 1700, 2156):
+    FRAMES["C5_rows%04d" % _r] = dict(W=3840, H=2160, row0=_r, rows=4, scene="rand10k", it=1, spp=256, fov=70.0, focal=3.0, aperture=0.05)
 
 
 def scene_arrays(name):
@@ -107,7 +114,7 @@ def frames(only=None):
     for name, spec in FRAMES.items():
         if only and name not in only:
             continue
-        modes = (1, 0) if name not in ("C4_band4", "C5_band4") else (1,)
+        modes = (1, 0) if not name.startswith(("C4_", "C5_")) else (1,)
         for contract in modes:
             key = "%s/%s" % (name, "fma" if contract else "strict")
             o = render(spec, contract)

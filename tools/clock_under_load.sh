@@ -17,13 +17,13 @@ while time.perf_counter() - t0 < 6.0:
 print("mixed: %.1f us/step" % ((time.perf_counter() - t0) / n * 1e6))
 PY
 sample; wait
-echo "== C3 every tile traced (RT_MI355X_NO_SUREHIT=1)"
-RT_MI355X_NO_SUREHIT=1 python3 - <<'PY' &
+echo "== C3 every tile traced (RT_FLAG_NO_SURE_HIT)"
+python3 - <<'PY' &
 import sys, time; sys.path.insert(0, ".")
 import raytracertest_amd as R
 from raytracertest_amd import scenes
 cfg = scenes.CONFIGS["C3"]
-g = R.RayTracer((1920, 1080), (0, 0, 0), cfg["angles"], cfg["fov"], cfg["focal"], cfg["aperture"], seed=1); g.UploadScene(scenes.cornell32())
+g = R.RayTracer((1920, 1080), (0, 0, 0), cfg["angles"], cfg["fov"], cfg["focal"], cfg["aperture"], seed=1, no_sure_hit=True); g.UploadScene(scenes.cornell32())
 t0 = time.perf_counter(); n = 0
 while time.perf_counter() - t0 < 6.0:
     for _ in range(1000): g.TraceEnqueue(1, 16)
