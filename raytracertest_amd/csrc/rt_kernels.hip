@@ -8,7 +8,7 @@
 //   dbg_* kernels      <- single-function harnesses used by the parity tests
 #include <stdlib.h>
 
-#include "rt_trace.hpp"
+#include "rt_dense.hpp"
 
 namespace rtk {
 
@@ -367,6 +367,23 @@ static void launch_trace_fused(const TraceParams& p, int K, dim3 grid, size_t ld
 
 bool trace_can_fuse(bool filter, bool bin) { return filter && bin; }
 
+// dense scenes with lists in HBM (rt_dense.hpp): default, un-instrumented launches only
+template <bool FMA, bool FUSE>
+static void launch_dense(const TraceParams& p, int K, dim3 grid, size_t lds, hipStream_t st) {
+#define RT_DENSE(KK) hipLaunchKernelGGL((trace_kernel<FMA, KK, true, false, true, false, FUSE, true, true>), grid, dim3(256), lds, st, p)
+  if (K == 1) RT_DENSE(1); else if (K == 2) RT_DENSE(2); else RT_DENSE(4);
+#undef RT_DENSE
+}
+
+hipError_t launch_wave_lists(const TraceParams& p, bool fma, hipStream_t st) {
+  if (p.wave_lists == nullptr || p.rows == 0u || p.W == 0u) return hipSuccess;
+  const dim3 grid(cdiv(p.W, 32), cdiv(p.rows, 8));
+  const size_t lds = static_cast<size_t>(p.block_list) * 4u + 160u;
+  if (fma) hipLaunchKernelGGL(wave_lists_kernel<true>, grid, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL(wave_lists_kernel<false>, grid, dim3(256), lds, st, p);
+  return hipGetLastError();
+}
+
 hipError_t launch_trace(const TraceParams& p, bool fma, bool filter, bool bin, int K, hipStream_t st) {
   // samples == 0 is a real launch, as in the reference (TraceKernel with sampleCount 0: counts += 0,
   // render += 0, RNG written back, Kernels.cuh:133-146): the fused clear / BGRA8 emit / list store of the
@@ -378,6 +395,13 @@ hipError_t launch_trace(const TraceParams& p, bool fma, bool filter, bool bin, i
     const uint32_t R = grid.y, G = p.row_il, full = R / (2u * G), rest = R % (2u * G);      // groups of G block rows, alternating
     grid.y = full * G + (p.row_phase == 0u ? (rest < G ? rest : G) : (rest > G ? rest - G : 0u));
     if (grid.y == 0u) return hipSuccess;
+  }
+  if (p.wave_lists != nullptr) {     // dense scenes, lists in HBM: no LDS, no classification in the trace kernel
+    if (!((p.flags & TRACE_PRETEST) && filter && bin && p.n_tris > p.bin_list) || p.stats != nullptr) return hipErrorInvalidValue;
+    const size_t lds_d = 4u * p.bin_list * 104u;                       // four waves' records + forms; no block list
+    if (p.iters > 1u) { if (fma) launch_dense<true, true>(p, K, grid, lds_d, st); else launch_dense<false, true>(p, K, grid, lds_d, st); }
+    else { if (fma) launch_dense<true, false>(p, K, grid, lds_d, st); else launch_dense<false, false>(p, K, grid, lds_d, st); }
+    return hipGetLastError();
   }
   const size_t lds = trace_lds_bytes(p, bin);
   if (p.iters > 1u) {                // fused iterations: default (filtered, classified, un-instrumented) kernels only

@@ -58,6 +58,11 @@ struct TraceParams {
   // small scenes: per triangle, what a pixel of a certain-winner tile accumulates in one launch of p.samples samples --
   // {sum.x, sum.y, sum.z, bits of the BGRA8 word of a freshly cleared pixel} (sure_table_kernel; null: the kernel adds)
   const float4* sure_table;
+  // dense scenes (the per-sample forms): the tiles' candidate lists in HBM, written by wave_lists_kernel and read by
+  // dense_trace_kernel (rt_dense.hpp): per tile slot of the launch grid (1 + wave_cap) records of 32 dwords; null: the
+  // trace kernel classifies on its own (instrumented launches, frames whose lists would not fit)
+  uint32_t* wave_lists;
+  uint32_t  wave_cap;
   uint32_t  flags;     // TRACE_*
 };
 
@@ -92,6 +97,8 @@ hipError_t launch_dbg_hit_triangle(bool fma, uint32_t n, const float* rays, cons
                                    int* hit, float* tuv, float* normal, float* point, hipStream_t st);
 bool trace_can_fuse(bool filter, bool bin);      // launches with TraceParams::iters > 1 are available
 hipError_t launch_macro_bin(const TraceParams& p, bool fma, hipStream_t st);
+// dense scenes: the per-wave candidate lists + forms of the (half-)launch `p` into p.wave_lists (after launch_macro_bin)
+hipError_t launch_wave_lists(const TraceParams& p, bool fma, hipStream_t st);
 // one wave that does nothing for `us` microseconds (bounded): the stagger of the first split launch after the tracer was idle
 hipError_t launch_delay(uint32_t us, hipStream_t st);
 // small scenes: hands the builder's per-half counts (TraceParams::half_cost) to the host -- *host_word = upper | lower << 32 --

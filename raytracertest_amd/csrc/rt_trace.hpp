@@ -29,6 +29,9 @@ namespace rtk {
 #ifndef RT_TRACE_WAVES
 #define RT_TRACE_WAVES(K) RT_TRACE_MIN_WAVES
 #endif
+#ifndef RT_HBM_WAVES
+#define RT_HBM_WAVES 4           // the dense-scene kernels that read their lists from HBM (A/B: 5 = at most 102 VGPRs)
+#endif
 #ifndef RT_SMALL_WG_WAVES
 #define RT_SMALL_WG_WAVES 4      // small-scene trace kernels: waves per workgroup (4, 2 or 1; see trace_kernel)
 #endif
@@ -157,8 +160,13 @@ __device__ __forceinline__ void test_triangle(const float4 A0, const float4 A1, 
 // PRE: large-scene kernels (BIN && !ONEPASS) with the per-sample forms; a separate instantiation because
 // the first classification then moves in front of the sample loop and the forms cost registers and code
 // that sparser scenes do not earn back (300-1000 triangles at 1080p: +6-10 % with them, C4: -13 %).
-template <bool FMA, int K, bool FILTER, bool STATS, bool BIN, bool ONEPASS, bool FUSE = false, bool PRE = false>
-__global__ __launch_bounds__((BIN && ONEPASS) ? 64 * RT_SMALL_WG_WAVES : 256, (ONEPASS && K == 2) ? 5 : RT_TRACE_WAVES(K)) void trace_kernel(const TraceParams p) {
+// HBM (PRE kernels only): the tiles' candidate lists + forms come from p.wave_lists (wave_lists_kernel, rt_dense.hpp) -- this
+// instantiation contains no classification and no barrier; a tile marked as overflowing tests its macro tile's list.
+constexpr uint32_t kWaveRec = 32u;                 // dwords per record of p.wave_lists
+constexpr uint32_t kWaveOverflow = 0xFFFFFFFFu;
+template <bool FMA, int K, bool FILTER, bool STATS, bool BIN, bool ONEPASS, bool FUSE = false, bool PRE = false, bool HBM = false>
+__global__ __launch_bounds__((BIN && ONEPASS) ? 64 * RT_SMALL_WG_WAVES : 256, (ONEPASS && K == 2) ? 5 : HBM ? RT_HBM_WAVES : RT_TRACE_WAVES(K)) void trace_kernel(const TraceParams p) {
+  static_assert(!HBM || (PRE && BIN && !ONEPASS && FILTER && !STATS), "lists from HBM: the default dense-scene kernels only");
   using M = Math<FMA>;
   extern __shared__ float4 s_mem[];
   // Small scenes: a 32 x 8 block of four tiles is traced by 4 / WGW workgroups of WGW waves (no wave of these kernels talks to
@@ -312,7 +320,29 @@ __global__ __launch_bounds__((BIN && ONEPASS) ? 64 * RT_SMALL_WG_WAVES : 256, (O
   const uint32_t n_src = src_count;  // triangles the block-level pre-cull walks over
   // (small-scene kernels load their tiles' lists and need no ray family at all)
   if constexpr (BIN && ONEPASS) fam.usable = false;
-  if constexpr (BIN && !ONEPASS) {
+  bool hbm_overflow = false;        // HBM: the tile's list did not fit its slot -> exact tests over the macro tile's list
+  if constexpr (HBM) {
+    const size_t slot = (static_cast<size_t>(by) * gxb + bx) * 4u + wave;
+    const float4* const rec = reinterpret_cast<const float4*>(p.wave_lists) + slot * (1u + p.wave_cap) * (kWaveRec / 4u);
+    const float4 hdr = rec[0];
+    const uint32_t count = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, hdr.x)));
+    hbm_overflow = count == kWaveOverflow;
+    fam.usable = true;
+    fam.fc[0] = uniform(hdr.y); fam.fc[1] = uniform(hdr.z); fam.fc[2] = uniform(hdr.w);
+    list_count = hbm_overflow ? 0u : count;
+    for (uint32_t e = lane; e < list_count; e += 64u) {              // the records into this wave's LDS slot, as classify() leaves them
+      const float4* const r = rec + (1u + e) * (kWaveRec / 4u);
+      const float4 f0 = r[0], f1 = r[1], f2 = r[2], f3 = r[3], a0 = r[4], a1 = r[5], b0 = r[6];
+      cP[4u * e] = f0; cP[4u * e + 1u] = f1; cP[4u * e + 2u] = f2; cP[4u * e + 3u] = make_float4(f3.x, f3.y, 0.0f, 0.0f);
+      cA[2u * e] = a0; cA[2u * e + 1u] = a1;
+      cB[e] = b0.x;
+      cI[e] = __builtin_bit_cast(int, f3.z);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // this wave's ds_writes before its ds_reads
+    __builtin_amdgcn_wave_barrier();
+    list_complete = true;
+  }
+  if constexpr (BIN && !ONEPASS && !HBM) {
     tl_mark(8);                                                    // loads issued, pinhole + focal point done
     const FocalBounds wb = focal_bounds(p, focal, inside);
     tl_mark(9);
@@ -452,11 +482,12 @@ __global__ __launch_bounds__((BIN && ONEPASS) ? 64 * RT_SMALL_WG_WAVES : 256, (O
   // all of them -- never classifies again; one that overflows falls back to rounds inside the
   // sample loop (lists rebuilt per batch, without forms).
   bool forms_ready = false;
-  if constexpr (PRETEST) {
+  if constexpr (PRETEST && !HBM) {
     const uint32_t next0 = classify(0u, std::true_type{});
     list_complete = next0 >= src_count;
     forms_ready = pretest && list_complete;
   }
+  if constexpr (HBM) forms_ready = true;
   if constexpr (RNG_LATE) load_rng();
   tl_mark(1);                                                      // family + classification done
   float4 sure_col = make_float4(0.0f, 0.0f, 0.0f, 0.0f);           // the winner's colour -- or, with the table, its p.samples-fold sum
@@ -516,14 +547,15 @@ __global__ __launch_bounds__((BIN && ONEPASS) ? 64 * RT_SMALL_WG_WAVES : 256, (O
       uint32_t base = 0;
       do {
         uint32_t next = src_count;
-        if (!list_complete) {
-          next = classify(base, std::false_type{});
-          if (base == 0u && next >= src_count) list_complete = true;     // (!PRE: the first classification happens here)
+        if constexpr (!HBM) {
+          if (!list_complete) {
+            next = classify(base, std::false_type{});
+            if (base == 0u && next >= src_count) list_complete = true;     // (!PRE: the first classification happens here)
+          }
         }
         // does ANY ray of the wave survive the per-sample forms of candidate j?  (wave-uniform)
-        auto forms_alive = [&](uint32_t j) -> bool {
+        auto forms_eval = [&](const float4 f0, const float4 f1, const float4 q2, const float4 q3) -> bool {
           // per-sample forms of this candidate at each ray's own lens origin: does ANY ray of the wave survive?
-          const float4 f0 = cP[4u * j], f1 = cP[4u * j + 1u], q2 = cP[4u * j + 2u], q3 = cP[4u * j + 3u];
           const float f2 = q2.x;
           // gradients: fp16 pairs read in place by v_fma_mix_f32 (op_sel picks the half): no unpack instructions
           typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -548,6 +580,7 @@ __global__ __launch_bounds__((BIN && ONEPASS) ? 64 * RT_SMALL_WG_WAVES : 256, (O
           if constexpr (STATS) { if (!alive) st_pre += 1; }
           return alive;
         };
+        auto forms_alive = [&](uint32_t j) -> bool { return forms_eval(cP[4u * j], cP[4u * j + 1u], cP[4u * j + 2u], cP[4u * j + 3u]); };
         auto run_tests = [&](uint32_t j) {
           const float4 A0 = cA[2u * j], A1 = cA[2u * j + 1u];
           test_triangle<FMA, K, FILTER, STATS>(A0, A1, [&] { return cB[j]; }, cI[j], o, d, best_t, best_i,
@@ -571,6 +604,17 @@ __global__ __launch_bounds__((BIN && ONEPASS) ? 64 * RT_SMALL_WG_WAVES : 256, (O
         base = next;
         if (!list_complete) __builtin_amdgcn_wave_barrier();       // list is rewritten by the next round
       } while (!list_complete && base < src_count);
+      if constexpr (HBM) {
+        if (hbm_overflow) {                                        // (wave-uniform, rare) every triangle of the macro tile's list, ascending
+          for (uint32_t e = 0; e < n_src; ++e) {
+            const uint32_t tri = mI != nullptr ? static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(mI[e]))) : e;
+            const float4 A0 = p.tri_a[2u * tri], A1 = p.tri_a[2u * tri + 1u];
+            const float bz = p.tri_b[tri];
+            test_triangle<FMA, K, FILTER, STATS>(A0, A1, [&] { return bz; }, static_cast<int>(tri), o, d, best_t, best_i,
+                                                 nearest, inside, valid_k, st_exit, st_skip);
+          }
+        }
+      }
     } else {
       for (uint32_t c0 = 0; c0 < n; c0 += p.chunk) {
         const uint32_t cn = (n - c0 < p.chunk) ? n - c0 : p.chunk;

@@ -140,6 +140,9 @@ struct Camera {
   }
 };
 
+#ifndef RT_PRETEST_LIST
+#define RT_PRETEST_LIST 92u      // per-wave list capacity of the dense-scene kernels with forms: 4 x 92 x 104 bytes = 38 KiB of LDS per block
+#endif
 struct EventPair { hipEvent_t a, b, c; uint32_t launches; bool split; uint64_t seq; };   // c: end of the lower half on stream_b
 
 // The render thread of a tracer.  The reference starts a std::thread per Trace and joins the previous one first
@@ -463,7 +466,7 @@ struct rt_tracer {
     // hence the size limit; C4 (10 k): 5.93 -> 5.66 ms.
     if (pretest && filter && bin && n_tris >= kPretestMinTris && n_tris <= 50000u) {
       p.pretest_on = 1u;
-      if (!bin_list_req) p.bin_list = 92u;
+      if (!bin_list_req) p.bin_list = RT_PRETEST_LIST;
       else p.bin_list = (p.bin_list + 1u) & ~1u;
       if (p.block_list != 0u) p.block_list = 448u;
     }
@@ -900,10 +903,41 @@ struct rt_tracer {
     k.W = p.W; k.H = p.H; k.row0 = p.row0; k.rows = p.rows; k.bin_list = p.macro_cap * 65536u + p.macro_w * 256u + p.macro_h; k.n_tris = p.n_tris;
     k.scene_generation = scene_generation; k.fma = fma;
     const bool same = macro_key_valid[half] && memcmp(&k, &macro_key[half], sizeof k) == 0 && !(first_launch_of_trace && !reuse_across_traces);
-    if (same) return;
-    macro_key[half] = k;
-    macro_key_valid[half] = true;
-    HIP_CHECK(rtk::launch_macro_bin(p, fma, st));
+    if (!same) {
+      macro_key[half] = k;
+      macro_key_valid[half] = true;
+      HIP_CHECK(rtk::launch_macro_bin(p, fma, st));
+    }
+    attach_wave_lists(p, half, st, !same);
+  }
+
+  // Dense scenes with the per-sample forms: the tiles' candidate lists (records + forms, 128 bytes per candidate) live in HBM,
+  // built by wave_lists_kernel behind the macro lists -- same key, same reuse rule -- and read by dense_trace_kernel through the
+  // scalar cache (rt_dense.hpp).  Sized for the list capacity, (1 + cap) x 128 bytes per tile: 1.5 GB for a 4K frame at cap 92
+  // (what a launch touches is the survivors: ~150 MB at C4); frames whose lists would exceed kWaveListsMaxBytes per half
+  // and instrumented launches keep the classification inside the trace kernel.
+  static constexpr size_t kWaveListsMaxBytes = size_t(6) << 30;
+  uint32_t* d_wave_lists[2] = {nullptr, nullptr};
+  size_t wave_lists_words[2] = {0, 0};
+  bool wave_lists_valid[2] = {false, false};
+  void attach_wave_lists(rtk::TraceParams& p, int half, hipStream_t st, bool macro_rebuilt) {
+    p.wave_lists = nullptr; p.wave_cap = 0u;
+    if (macro_rebuilt) wave_lists_valid[half] = false;                  // (also when this launch does not use them: they follow the macro lists' key)
+    if (!p.pretest_on || p.stats != nullptr || p.macro_lists == nullptr) return;
+    const size_t tiles = static_cast<size_t>((p.W + 31u) / 32u) * ((p.rows + 7u) / 8u) * 4u;
+    const size_t words = tiles * (1u + p.bin_list) * 32u;
+    if (words * sizeof(uint32_t) > kWaveListsMaxBytes) return;
+    if (words > wave_lists_words[half]) {                                // (hipFree waits for the device: safe while the other half runs)
+      if (d_wave_lists[half]) (void)hipFree(d_wave_lists[half]);
+      d_wave_lists[half] = nullptr; wave_lists_words[half] = 0; wave_lists_valid[half] = false;
+      HIP_CHECK(hipMalloc(&d_wave_lists[half], words * sizeof(uint32_t)));
+      wave_lists_words[half] = words;
+    }
+    p.wave_lists = d_wave_lists[half]; p.wave_cap = p.bin_list;
+    if (!wave_lists_valid[half]) {
+      HIP_CHECK(rtk::launch_wave_lists(p, fma, st));
+      wave_lists_valid[half] = true;
+    }
   }
 
   static constexpr int kWindow = 4;
@@ -1254,6 +1288,7 @@ void rt_tracer_destroy(rt_tracer* t) {                                   // RayT
   if (t->d_half_cost) (void)hipFree(t->d_half_cost);
   if (t->h_half_cost) (void)hipHostFree(t->h_half_cost);
   for (int h = 0; h < 2; ++h) if (t->d_macro_lists[h]) (void)hipFree(t->d_macro_lists[h]);
+  for (int h = 0; h < 2; ++h) if (t->d_wave_lists[h]) (void)hipFree(t->d_wave_lists[h]);
   if (t->d_tri_n) (void)hipFree(t->d_tri_n);
   if (t->d_tri) (void)hipFree(t->d_tri);
   if (t->d_tri_b) (void)hipFree(t->d_tri_b);

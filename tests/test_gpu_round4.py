@@ -204,3 +204,54 @@ def test_render_thread_is_reused_and_keeps_the_contract(rt, orc):
     g.Trace(300000, 1, 0); g.Stop()
     assert not g.Wait() and len(seen) == n0 + 1            # a stopped run fires no finished callback (:280-284)
     g.close()
+
+
+def _dense_pair(rt, W, H, n_tris, seed, **kw):
+    from raytracertest_amd import scenes
+    scn = scenes.random_triangles(n_tris, seed)
+    g = rt.RayTracer((W, H), (0, 0, 0), (0.1, -0.05), 70.0, 3.0, 0.05, seed=8, **kw)
+    ref = rt.RayTracer((W, H), (0, 0, 0), (0.1, -0.05), 70.0, 3.0, 0.05, seed=8, no_binning=True)
+    assert g.UploadScene(scn) and ref.UploadScene(scn)
+    return g, ref
+
+
+def _same(g, ref):
+    for name, a, b in zip(("render", "counts", "rng", "image"), buffers(g), buffers(ref)):
+        assert np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32)), name
+
+
+def test_dense_lists_in_hbm_are_kept_across_launches_and_rebuilt_when_the_view_changes(rt):
+    """Dense scenes keep their per-wave candidate lists + forms in HBM (wave_lists_kernel, keyed like the macro lists): a Trace
+    of several launches classifies once, a camera change or a new scene rebuilds -- every state against the full scan."""
+    from raytracertest_amd import scenes
+    g, ref = _dense_pair(rt, 200, 136, 6000, 31)
+    for t in (g, ref):
+        t.Trace(20, 8, 0); assert t.Wait()                 # 160 spp: three launches of fused iterations, the lists built by the first
+    _same(g, ref)
+    for t in (g, ref):
+        t.RotateCamera((0.07, 0.03))
+        t.TraceEnqueue(2, 5); t.TraceEnqueue(1, 3); t.Sync()
+    _same(g, ref)
+    scn2 = scenes.random_triangles(5000, 99)
+    for t in (g, ref):
+        assert t.UploadScene(scn2)
+        t.SetCameraParameters(60.0, 2.5, 0.08)
+        t.Trace(3, 2, 2); assert t.Wait()                  # update cadence: un-fused launches
+    _same(g, ref)
+    for t in (g, ref):
+        t.Resize((168, 130))
+        t.Launch(4, clear_first=True); t.Launch(4, emit_image=True); t.Sync()
+    _same(g, ref)
+    g.close(); ref.close()
+
+
+def test_dense_list_overflow_falls_back_to_the_macro_list(rt):
+    """A tile whose candidates exceed the list capacity is marked by wave_lists_kernel and traced with the exact tests over its
+    macro tile's list: 20 000 triangles on a 96x64 frame with the smallest capacity (32) overflow every tile; 6 000 on 200x136
+    overflow some.  Both against the full scan, split and unsplit launches."""
+    for W, H, n, seed in ((96, 64, 20000, 5), (200, 136, 6000, 31)):
+        g, ref = _dense_pair(rt, W, H, n, seed, bin_list=32)
+        for t in (g, ref):
+            t.TraceEnqueue(2, 5); t.Sync()
+        _same(g, ref)
+        g.close(); ref.close()
