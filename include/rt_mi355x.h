@@ -304,6 +304,10 @@ int rt_dbg_valu_peak(int device, double* lane_fma_per_s, double* clock_ghz);
  * [2^-96, 2^96] against the generic correctly rounded expansions.  out = {values checked, sqrt mismatches,
  * reciprocal mismatches, bit pattern of a mismatching operand or 0}. */
 int rt_dbg_check_midrange(int device, uint64_t out[4]);
+/* Dense scenes: the header words (candidate count; 0xFFFFFFFF = the list overflowed its capacity and the tile tests its macro
+ * tile's list) of the per-wave lists in HBM as the last launch left them; half 0 = an unsplit launch or the upper half of a split
+ * one, 1 = the lower half.  Measurement aid and tests. */
+int rt_dbg_wave_list_counts(rt_tracer* t, int half, uint32_t* dst, size_t capacity_tiles, uint32_t* n_tiles, uint32_t* capacity_per_tile);
 /* The stored tile candidate lists of a small-scene tracer (after a launch that stored them): per 8x8 wave tile, in grid
  * order (4 per 32x8 block), *words_per_tile words: count | winner << 10 | certain-winner << 31, then the triangle indices. */
 int rt_dbg_read_tile_lists(rt_tracer* t, uint32_t* dst, size_t capacity_words, uint32_t* words_per_tile);

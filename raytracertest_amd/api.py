@@ -44,7 +44,7 @@ ABI_SYMBOLS = [
     "rt_dbg_rng_init_host",
     "rt_tracer_create_multi", "rt_group_unique_id", "rt_tracer_join_group", "rt_tracer_leave_group",
     "rt_tracer_gather_time", "rt_tracer_band_count", "rt_tracer_band_info",
-    "rt_tracer_join_group_bands", "rt_balance_rows", "rt_tracer_rebalance", "rt_tracer_set_band", "rt_dbg_read_tile_lists", "rt_dbg_focal_boxes", "rt_dbg_classify",
+    "rt_tracer_join_group_bands", "rt_balance_rows", "rt_tracer_rebalance", "rt_tracer_set_band", "rt_dbg_read_tile_lists", "rt_dbg_wave_list_counts", "rt_dbg_focal_boxes", "rt_dbg_classify",
     "rt_tracer_gather_only", "rt_tracer_group_info",
 ]
 
@@ -185,6 +185,7 @@ def load_library():
         L.rt_tracer_rebalance.argtypes = [vp]
         L.rt_tracer_set_band.argtypes = [vp, C.c_uint32, C.c_uint32]
         L.rt_dbg_read_tile_lists.argtypes = [vp, u32p, C.c_size_t, u32p]
+        L.rt_dbg_wave_list_counts.argtypes = [vp, C.c_int, u32p, C.c_size_t, u32p, u32p]
         L.rt_dbg_focal_boxes.argtypes = [vp, C.c_float, f32p, C.c_size_t, f32p, C.c_size_t]
         L.rt_tracer_gather_only.argtypes = [vp]
         L.rt_tracer_group_info.argtypes = [vp, C.c_char_p, C.c_size_t]
@@ -488,6 +489,14 @@ class RayTracer:
         w = int(wpt[0])
         words = buf[:bx * by * 4 * w].reshape(by, bx * 4, w)[:, :, 0]
         return (words & 0x3FF).astype(np.int32), ((words >> 10) & 0x3FF).astype(np.int32), (words >> 31).astype(bool)
+
+    def DebugWaveListCounts(self, half=0):
+        """(counts, capacity): candidate count per tile (grid order of the half's launch; 0xFFFFFFFF = overflow) of a dense scene's
+        lists in HBM (rt_dbg_wave_list_counts)."""
+        n, cap = np.zeros(1, np.uint32), np.zeros(1, np.uint32)
+        buf = np.zeros(((self.width + 31) // 32) * ((self.rows + 7) // 8 + 1) * 4, np.uint32)
+        self._check(self._lib.rt_dbg_wave_list_counts(self._h, half, _u32p(buf), buf.size, _u32p(n), _u32p(cap)))
+        return buf[:int(n[0])].copy(), int(cap[0])
 
     def DebugTileListWords(self):
         """(tiles_y, tiles_x, 1 + bin_list) words of the stored tile lists: word 0 = count | winner << 10 | certain << 31, then

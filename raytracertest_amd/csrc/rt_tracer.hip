@@ -1962,6 +1962,26 @@ int rt_dbg_read_tile_lists(rt_tracer* t, uint32_t* dst, size_t capacity_words, u
   });
 }
 
+// dense scenes: the header words (candidate count, 0xFFFFFFFF = overflow) of the tiles' lists in HBM as the last launch left
+// them -- half 0 = the unsplit launch or the upper half of a split one, half 1 = the lower half.  Measurement aid / tests.
+int rt_dbg_wave_list_counts(rt_tracer* t, int half, uint32_t* dst, size_t capacity_tiles, uint32_t* n_tiles, uint32_t* capacity_per_tile) {
+  if (!t || t->mg || !dst || half < 0 || half > 1) return RT_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(t->api_mu);
+  return guarded(t, [&] {
+    t->cancel_and_join();
+    t->use_device();
+    HIP_CHECK(hipStreamSynchronize(t->main_stream()));
+    if (!t->d_wave_lists[half] || !t->wave_lists_valid[half]) throw HipFail{"no wave lists (dense scenes build them ahead of their first trace launch)"};
+    const rt_tracer::ListKey& k = t->macro_key[half];
+    const size_t tiles = static_cast<size_t>((k.W + 31u) / 32u) * ((k.rows + 7u) / 8u) * 4u;
+    const uint32_t cap = t->params(1).bin_list;
+    const size_t n = tiles < capacity_tiles ? tiles : capacity_tiles;
+    HIP_CHECK(hipMemcpy2D(dst, sizeof(uint32_t), t->d_wave_lists[half], static_cast<size_t>(1u + cap) * 128u, sizeof(uint32_t), n, hipMemcpyDeviceToHost));
+    if (n_tiles) *n_tiles = static_cast<uint32_t>(tiles);
+    if (capacity_per_tile) *capacity_per_tile = cap;
+  });
+}
+
 int rt_dbg_trace_occupancy(int device, int samples_in_flight, uint32_t lds_bytes) {
   if (require_device(device) != RT_OK) return -1;
   if (hipSetDevice(device) != hipSuccess) return -1;

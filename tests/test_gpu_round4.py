@@ -254,4 +254,9 @@ def test_dense_list_overflow_falls_back_to_the_macro_list(rt):
         for t in (g, ref):
             t.TraceEnqueue(2, 5); t.Sync()
         _same(g, ref)
+        counts, cap = g.DebugWaveListCounts(0)
+        over = counts == 0xFFFFFFFF
+        assert cap == 32 and over.any() and (counts[~over] <= cap).all(), (cap, int(over.sum()), counts.size)
+        if n == 20000:
+            assert over.mean() > 0.9                       # the fallback is what this frame ran
         g.close(); ref.close()

@@ -26,6 +26,14 @@ for rep in range(3):
     ts = np.array(ts) * 1e6
     print("rep %d: %d steps: enqueue %.1f us/step (first 20: %.1f, last 100 median %.1f, max %.0f), drained total %.1f us/step"
           % (rep, steps, enq / steps * 1e6, ts[:20].mean(), np.median(ts[-100:]), ts.max(), tot / steps * 1e6))
+# the loop inside the library (rt_tracer_trace_enqueue_n, what bench.py's timed region calls): one ctypes crossing for all steps
+for rep in range(3):
+    g.Sync(); t0 = time.perf_counter()
+    g.TraceEnqueueN(1, 16, steps)
+    enq = time.perf_counter() - t0
+    g.Sync()
+    tot = time.perf_counter() - t0
+    print("TraceEnqueueN rep %d: %d steps: enqueue %.1f us/step inside the library, drained total %.1f us/step" % (rep, steps, enq / steps * 1e6, tot / steps * 1e6))
 for n in (20, 20, 20, 50, 100):
     g.Sync(); t0 = time.perf_counter()
     for _ in range(n): g.TraceEnqueue(1, 16)
