@@ -398,7 +398,7 @@ hipError_t launch_trace(const TraceParams& p, bool fma, bool filter, bool bin, i
   }
   if (p.wave_lists != nullptr) {     // dense scenes, lists in HBM: no LDS, no classification in the trace kernel
     if (!((p.flags & TRACE_PRETEST) && filter && bin && p.n_tris > p.bin_list) || p.stats != nullptr) return hipErrorInvalidValue;
-    const size_t lds_d = 4u * p.bin_list * 104u;                       // four waves' records + forms; no block list
+    const size_t lds_d = 4u * p.bin_list * 116u;                       // four waves' records + forms + colours; no block list
     if (p.iters > 1u) { if (fma) launch_dense<true, true>(p, K, grid, lds_d, st); else launch_dense<false, true>(p, K, grid, lds_d, st); }
     else { if (fma) launch_dense<true, false>(p, K, grid, lds_d, st); else launch_dense<false, false>(p, K, grid, lds_d, st); }
     return hipGetLastError();

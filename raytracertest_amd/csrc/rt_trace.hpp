@@ -162,7 +162,7 @@ __device__ __forceinline__ void test_triangle(const float4 A0, const float4 A1, 
 // that sparser scenes do not earn back (300-1000 triangles at 1080p: +6-10 % with them, C4: -13 %).
 // HBM (PRE kernels only): the tiles' candidate lists + forms come from p.wave_lists (wave_lists_kernel, rt_dense.hpp) -- this
 // instantiation contains no classification and no barrier; a tile marked as overflowing tests its macro tile's list.
-constexpr uint32_t kWaveRec = 32u;                 // dwords per record of p.wave_lists
+constexpr uint32_t kWaveRec = 28u;                 // dwords per record of p.wave_lists
 constexpr uint32_t kWaveOverflow = 0xFFFFFFFFu;
 template <bool FMA, int K, bool FILTER, bool STATS, bool BIN, bool ONEPASS, bool FUSE = false, bool PRE = false, bool HBM = false>
 __global__ __launch_bounds__((BIN && ONEPASS) ? 64 * RT_SMALL_WG_WAVES : 256, (ONEPASS && K == 2) ? 5 : HBM ? RT_HBM_WAVES : RT_TRACE_WAVES(K)) void trace_kernel(const TraceParams p) {
@@ -289,6 +289,11 @@ __global__ __launch_bounds__((BIN && ONEPASS) ? 64 * RT_SMALL_WG_WAVES : 256, (O
   const bool pretest = PRETEST && (p.flags & TRACE_PRETEST) != 0u;   // wave-uniform
   float4* const cP = s_mem + 4u * 2u * L + 2u * L + static_cast<size_t>(wave) * (4u * L);   // after cA (8L float4), cB + cI (2L float4)
   const uint32_t list_floats4 = pretest ? (4u * 2u * L + 2u * L + 16u * L) : (4u * 2u * L + 2u * L);   // float4 units before the block list
+  // HBM: the candidates' colours travel with them (3 floats each, behind the forms: this instantiation has no block list).  A
+  // hit is remembered as its SLOT in the wave's list -- ascending like the triangle indices, so ties break the same way -- and
+  // shaded from LDS: the per-sample gather p.tri_color[winner] was an exposed global-memory round trip per sample batch
+  // (24 % of the dense-scene kernel's wave cycles sat in s_waitcnt: profiles/r04_c4_stalls.txt).
+  float* const cC = reinterpret_cast<float*>(s_mem + list_floats4) + wave * (3u * L);
 
   TileFamily fam;
   bool list_complete = false;       // the list in LDS covers the whole scene (classification done once)
@@ -332,11 +337,12 @@ __global__ __launch_bounds__((BIN && ONEPASS) ? 64 * RT_SMALL_WG_WAVES : 256, (O
     list_count = hbm_overflow ? 0u : count;
     for (uint32_t e = lane; e < list_count; e += 64u) {              // the records into this wave's LDS slot, as classify() leaves them
       const float4* const r = rec + (1u + e) * (kWaveRec / 4u);
-      const float4 f0 = r[0], f1 = r[1], f2 = r[2], f3 = r[3], a0 = r[4], a1 = r[5], b0 = r[6];
+      const float4 f0 = r[0], f1 = r[1], f2 = r[2], f3 = r[3], a0 = r[4], a1 = r[5], c0 = r[6];
       cP[4u * e] = f0; cP[4u * e + 1u] = f1; cP[4u * e + 2u] = f2; cP[4u * e + 3u] = make_float4(f3.x, f3.y, 0.0f, 0.0f);
       cA[2u * e] = a0; cA[2u * e + 1u] = a1;
-      cB[e] = b0.x;
+      cB[e] = f3.w;
       cI[e] = __builtin_bit_cast(int, f3.z);
+      cC[3u * e] = c0.x; cC[3u * e + 1u] = c0.y; cC[3u * e + 2u] = c0.z;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // this wave's ds_writes before its ds_reads
     __builtin_amdgcn_wave_barrier();
@@ -530,6 +536,9 @@ __global__ __launch_bounds__((BIN && ONEPASS) ? 64 * RT_SMALL_WG_WAVES : 256, (O
     }
 
     const unsigned long long lanes_in = __builtin_amdgcn_ballot_w64(inside);   // (wave constant: hoisted)
+    unsigned long long pad_mask[K];                                 // PRETEST: all ones for the padding samples of a partial batch (they never keep a candidate alive)
+#pragma unroll
+    for (int k = 0; k < K; ++k) pad_mask[k] = (static_cast<uint32_t>(k) < valid_k) ? 0ull : ~0ull;
     float dox[K], doy[K];                                           // PRETEST: each ray's lens offset do = o - oc
     float dFx = 0.0f, dFy = 0.0f, dFz = 0.0f;                       // PRETEST: this lane's focal point minus the tile's box centre
     if constexpr (PRETEST) {
@@ -574,7 +583,7 @@ __global__ __launch_bounds__((BIN && ONEPASS) ? 64 * RT_SMALL_WG_WAVES : 256, (O
             const float F2 = __builtin_fmaf(f1.y, doy[k], __builtin_fmaf(f1.x, dox[k], b2));
             const float F3 = __builtin_fmaf(f2, doy[k], __builtin_fmaf(f1.w, dox[k], b3));
             const float worst = __builtin_fminf(__builtin_fminf(F1, F2), F3);
-            all_neg &= __builtin_amdgcn_ballot_w64(worst < 0.0f) | ((static_cast<uint32_t>(k) < valid_k) ? 0ull : ~0ull);
+            all_neg &= __builtin_amdgcn_ballot_w64(worst < 0.0f) | pad_mask[k];
           }
           const bool alive = (~all_neg & lanes_in) != 0ull;
           if constexpr (STATS) { if (!alive) st_pre += 1; }
@@ -583,7 +592,7 @@ __global__ __launch_bounds__((BIN && ONEPASS) ? 64 * RT_SMALL_WG_WAVES : 256, (O
         auto forms_alive = [&](uint32_t j) -> bool { return forms_eval(cP[4u * j], cP[4u * j + 1u], cP[4u * j + 2u], cP[4u * j + 3u]); };
         auto run_tests = [&](uint32_t j) {
           const float4 A0 = cA[2u * j], A1 = cA[2u * j + 1u];
-          test_triangle<FMA, K, FILTER, STATS>(A0, A1, [&] { return cB[j]; }, cI[j], o, d, best_t, best_i,
+          test_triangle<FMA, K, FILTER, STATS>(A0, A1, [&] { return cB[j]; }, HBM ? static_cast<int>(j) : cI[j], o, d, best_t, best_i,
                                                nearest, inside, valid_k, st_exit, st_skip);
         };
         if (forms_ready) {
@@ -638,19 +647,23 @@ __global__ __launch_bounds__((BIN && ONEPASS) ? 64 * RT_SMALL_WG_WAVES : 256, (O
       if (static_cast<uint32_t>(k) < valid_k) {
         float dist = best_t[k];
         int win = best_i[k];
+        // (HBM: a triangle hit is its slot in the wave's list -- unless the tile overflowed and tested triangles by index)
+        const bool by_slot = HBM && !hbm_overflow;                  // wave-uniform
+        const int first_sphere = by_slot ? 0x40000000 : static_cast<int>(n);
         for (uint32_t si = 0; si < p.n_spheres; ++si) {
           float t = 0.0f;
           if (hit_sphere<FMA>(o[k], d[k], p.spheres[si], t) && (nearest ? (t > 0.0f && t < dist) : dist < t)) {
             dist = t;
-            win = static_cast<int>(n + si);
+            win = first_sphere + static_cast<int>(si);
           }
         }
         float r, g, b;
         if (win >= 0) {
-          if (win < static_cast<int>(n)) {
+          if (win < first_sphere) {
             if (p.tri_n != nullptr) {
               // build-defined smooth shading: vertex normals interpolated at the winner's barycentrics;
               // u, v are recomputed from the winner's record (same arithmetic as the scan: same bits)
+              if (by_slot) win = cI[win];
               const float4 A0 = p.tri_a[2 * win], A1 = p.tri_a[2 * win + 1];
               float t = 0.0f, u = 0.0f, v = 0.0f;
               int stage;
@@ -670,12 +683,14 @@ __global__ __launch_bounds__((BIN && ONEPASS) ? 64 * RT_SMALL_WG_WAVES : 256, (O
               }
               const V3 nn = M::normalize(m);
               r = rtd::absf(nn.x); g = rtd::absf(nn.y); b = rtd::absf(nn.z);
+            } else if (by_slot) {
+              r = cC[3 * win]; g = cC[3 * win + 1]; b = cC[3 * win + 2];
             } else {
               const float4 col = p.tri_color[win];
               r = col.x; g = col.y; b = col.z;
             }
           } else {
-            const float4 sph = p.spheres[win - static_cast<int>(n)];
+            const float4 sph = p.spheres[win - first_sphere];
             const V3 hp = {M::madd1(d[k].x, dist, o[k].x), M::madd1(d[k].y, dist, o[k].y),
                            M::madd1(d[k].z, dist, o[k].z)};                 // Ray::point, Ray.cuh:41-44
             const V3 nn = M::normalize(rtd::sub(hp, {sph.x, sph.y, sph.z}));

@@ -6,13 +6,13 @@
 # profiles/valu_issue.json stamped with the kernel hash) -> the bench lines, so that every line this script keeps carries the
 # PMC figures of the build it ran on.  Everything to keep ends up under gpurun_out/<tag>/profiles/ (copy it into profiles/).
 set -o pipefail
-TAG=${1:-r03_x}
+TAG=${1:-r04_x}
 export TMPDIR=/tmp
 O=$PWD/gpurun_out/$TAG
 S=/tmp/rt_prof_$TAG                       # raw profiler output stays on the box (the kernel traces are large)
 rm -rf "$O" "$S"; mkdir -p "$O" "$S"
-B="python3 bench.py --cpu-rows 0 --no-valu --no-warm --no-parity"   # profiled runs: headline launches only
-python3 bench.py --no-valu --cpu-rows 0 > "$O/bench_c3.json" 2> "$O/bench_c3.err" || exit 1      # (library hash for the summary)
+B="python3 bench.py --cpu-rows 0 --no-valu --no-warm --no-parity --no-c4 --no-e2e"   # profiled runs: headline launches only
+python3 bench.py --no-valu --cpu-rows 0 --no-c4 --no-e2e > "$O/bench_c3.json" 2> "$O/bench_c3.err" || exit 1      # (library hash for the summary)
 echo "stats C3";  rocprofv3 --kernel-trace --stats --output-format csv -d "$S/stats" -- $B --steps 50 --warmup 5 > "$O/stats.log" 2>&1 || exit 1
 echo "pmc C3";    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$S/pmc_fetch" -- $B --steps 5 --warmup 1 > "$O/pmc_fetch.log" 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$S/pmc_write" -- $B --steps 5 --warmup 1 > "$O/pmc_write.log" 2>&1 || exit 1
@@ -22,6 +22,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$S/stats_c4" -- $B --co
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$S/pmc_fetch_c4" -- $B --config C4 --steps 3 --warmup 1 > "$O/pmc_fetch_c4.log" 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$S/pmc_write_c4" -- $B --config C4 --steps 3 --warmup 1 > "$O/pmc_write_c4.log" 2>&1 || exit 1
 grep '^{"metric"' "$O/stats.log" > "$O/bench_c3_under_rocprof.json"
+python3 tools/step_periods.py "$S/stats" > "profiles/${TAG}_c3_step_periods.txt" 2>&1 || true
 echo "summary";   python3 tools/pmc_summary.py "$TAG" "$S" > "$O/pmc_summary.log" 2>&1 || { cat "$O/pmc_summary.log"; exit 1; }
 echo "bench";     python3 bench.py > "profiles/${TAG}_bench_c3.json" 2> "$O/bench_c3_final.err" || exit 1
 python3 bench.py --steps 20 --warmup 5 > "profiles/${TAG}_bench_c3_steps20.json" 2>> "$O/bench_c3_final.err" || exit 1
