@@ -6,7 +6,7 @@
 // forms in LDS.  The lists depend on camera, scene and frame, not on the samples -- like the macro lists and the small scenes'
 // tile lists they are an acceleration structure -- so wave_lists_kernel runs that three-level classification once per key (the
 // same focal_bounds, make_family, block pre-cull and tile_misses_triangle calls, the same forms) and writes per 8x8 tile a
-// header and the survivors, ascending, 112 bytes each; the trace kernel's HBM instantiation contains no classification and no
+// header and the survivors, ascending, 64 bytes each; the trace kernel's HBM instantiation contains no classification and no
 // barrier: a wave copies its tile's records into its LDS slot and runs the candidate loop of round 3.  Accumulating launches
 // of a Trace (and, with list reuse across Traces, every launch of an unchanged view) skip the build.
 // A tile whose survivors exceed the list's capacity is marked and falls back to the exact tests over its macro tile's list
@@ -15,10 +15,11 @@
 // into SGPRs that the VALU takes as operands, no LDS at all -- is bit-identical and 13 % slower: 16 waves x 8.8 candidates x
 // 128 bytes cycle through a 16 KiB scalar cache that two CUs share.)
 //
-// Layout of p.wave_lists, per tile slot of the (half-)launch grid, (1 + wave_cap) records of 28 dwords (112 bytes):
+// Layout of p.wave_lists, per tile slot of the (half-)launch grid, (1 + wave_cap) records of 16 dwords (64 bytes):
 //   header     [0] count (0xFFFFFFFF = overflow)  [1..3] fc = centre of the tile's focal box (the forms' dF = F - fc)
 //   candidate  [0..13] the forms exactly as the LDS slot holds them (9 floats, 5 words of fp16 gradient pairs)  [14] triangle index
-//              [15] v0.z  [16..23] (e2.xyz, e1.x), (e1.yz, v0.xy)  [24..26] the triangle's colour abs(normalize(cross(e1, e2)))
+// (the triangle's 36-byte record and its colour are gathered from the scene's own tables -- 640 KB at C4, L2-resident -- when
+//  the wave loads its list: what travels through HBM per build is the forms)
 #pragma once
 #include "rt_trace.hpp"
 
@@ -117,10 +118,7 @@ __global__ __launch_bounds__(256) void wave_lists_kernel(const TraceParams p) {
       r[0] = make_float4(forms[0], forms[1], forms[2], forms[3]);
       r[1] = make_float4(forms[4], forms[5], forms[6], forms[7]);
       r[2] = make_float4(forms[8], pk(forms[9], forms[10]), pk(forms[11], forms[12]), pk(forms[13], forms[14]));
-      r[3] = make_float4(pk(forms[15], forms[16]), pk(forms[17], 0.0f), __builtin_bit_cast(float, tri), bz);
-      r[4] = A0;
-      r[5] = A1;
-      r[6] = p.tri_color[tri];                                       // the shade of a hit (Kernels.cuh:97-99): travels with the candidate
+      r[3] = make_float4(pk(forms[15], forms[16]), pk(forms[17], 0.0f), __builtin_bit_cast(float, tri), 0.0f);
     }
     count += static_cast<uint32_t>(__builtin_popcountll(m));
   }

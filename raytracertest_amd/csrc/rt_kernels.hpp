@@ -59,7 +59,7 @@ struct TraceParams {
   // {sum.x, sum.y, sum.z, bits of the BGRA8 word of a freshly cleared pixel} (sure_table_kernel; null: the kernel adds)
   const float4* sure_table;
   // dense scenes (the per-sample forms): the tiles' candidate lists in HBM, written by wave_lists_kernel and read by
-  // dense_trace_kernel (rt_dense.hpp): per tile slot of the launch grid (1 + wave_cap) records of 28 dwords; null: the
+  // dense_trace_kernel (rt_dense.hpp): per tile slot of the launch grid (1 + wave_cap) records of 16 dwords; null: the
   // trace kernel classifies on its own (instrumented launches, frames whose lists would not fit)
   uint32_t* wave_lists;
   uint32_t  wave_cap;

@@ -162,7 +162,7 @@ __device__ __forceinline__ void test_triangle(const float4 A0, const float4 A1, 
 // that sparser scenes do not earn back (300-1000 triangles at 1080p: +6-10 % with them, C4: -13 %).
 // HBM (PRE kernels only): the tiles' candidate lists + forms come from p.wave_lists (wave_lists_kernel, rt_dense.hpp) -- this
 // instantiation contains no classification and no barrier; a tile marked as overflowing tests its macro tile's list.
-constexpr uint32_t kWaveRec = 28u;                 // dwords per record of p.wave_lists
+constexpr uint32_t kWaveRec = 16u;                 // dwords per record of p.wave_lists
 constexpr uint32_t kWaveOverflow = 0xFFFFFFFFu;
 template <bool FMA, int K, bool FILTER, bool STATS, bool BIN, bool ONEPASS, bool FUSE = false, bool PRE = false, bool HBM = false>
 __global__ __launch_bounds__((BIN && ONEPASS) ? 64 * RT_SMALL_WG_WAVES : 256, (ONEPASS && K == 2) ? 5 : HBM ? RT_HBM_WAVES : RT_TRACE_WAVES(K)) void trace_kernel(const TraceParams p) {
@@ -337,11 +337,14 @@ __global__ __launch_bounds__((BIN && ONEPASS) ? 64 * RT_SMALL_WG_WAVES : 256, (O
     list_count = hbm_overflow ? 0u : count;
     for (uint32_t e = lane; e < list_count; e += 64u) {              // the records into this wave's LDS slot, as classify() leaves them
       const float4* const r = rec + (1u + e) * (kWaveRec / 4u);
-      const float4 f0 = r[0], f1 = r[1], f2 = r[2], f3 = r[3], a0 = r[4], a1 = r[5], c0 = r[6];
+      const float4 f0 = r[0], f1 = r[1], f2 = r[2], f3 = r[3];
+      const uint32_t tri = __builtin_bit_cast(uint32_t, f3.z);
+      const float4 a0 = p.tri_a[2u * tri], a1 = p.tri_a[2u * tri + 1u], c0 = p.tri_color[tri];   // (the scene's tables: L2-resident)
+      const float bz = p.tri_b[tri];
       cP[4u * e] = f0; cP[4u * e + 1u] = f1; cP[4u * e + 2u] = f2; cP[4u * e + 3u] = make_float4(f3.x, f3.y, 0.0f, 0.0f);
       cA[2u * e] = a0; cA[2u * e + 1u] = a1;
-      cB[e] = f3.w;
-      cI[e] = __builtin_bit_cast(int, f3.z);
+      cB[e] = bz;
+      cI[e] = static_cast<int>(tri);
       cC[3u * e] = c0.x; cC[3u * e + 1u] = c0.y; cC[3u * e + 2u] = c0.z;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // this wave's ds_writes before its ds_reads

@@ -911,10 +911,10 @@ struct rt_tracer {
     attach_wave_lists(p, half, st, !same);
   }
 
-  // Dense scenes with the per-sample forms: the tiles' candidate lists (records + forms + colour, 112 bytes per candidate) live in HBM,
+  // Dense scenes with the per-sample forms: the tiles' candidate lists (forms + triangle index, 64 bytes per candidate) live in HBM,
   // built by wave_lists_kernel behind the macro lists -- same key, same reuse rule -- and read by dense_trace_kernel through the
-  // scalar cache (rt_dense.hpp).  Sized for the list capacity, (1 + cap) x 112 bytes per tile: 1.2 GB for a 4K frame at cap 84
-  // (what a launch touches is the survivors: ~130 MB at C4); frames whose lists would exceed kWaveListsMaxBytes per half
+  // scalar cache (rt_dense.hpp).  Sized for the list capacity, (1 + cap) x 64 bytes per tile: 0.7 GB for a 4K frame at cap 84
+  // (what a launch touches is the survivors: ~75 MB at C4); frames whose lists would exceed kWaveListsMaxBytes per half
   // and instrumented launches keep the classification inside the trace kernel.
   static constexpr size_t kWaveListsMaxBytes = size_t(6) << 30;
   uint32_t* d_wave_lists[2] = {nullptr, nullptr};
@@ -925,7 +925,7 @@ struct rt_tracer {
     if (macro_rebuilt) wave_lists_valid[half] = false;                  // (also when this launch does not use them: they follow the macro lists' key)
     if (!p.pretest_on || p.stats != nullptr || p.macro_lists == nullptr) return;
     const size_t tiles = static_cast<size_t>((p.W + 31u) / 32u) * ((p.rows + 7u) / 8u) * 4u;
-    const size_t words = tiles * (1u + p.bin_list) * 28u;
+    const size_t words = tiles * (1u + p.bin_list) * 16u;
     if (words * sizeof(uint32_t) > kWaveListsMaxBytes) return;
     if (words > wave_lists_words[half]) {                                // (hipFree waits for the device: safe while the other half runs)
       if (d_wave_lists[half]) (void)hipFree(d_wave_lists[half]);
@@ -1976,7 +1976,7 @@ int rt_dbg_wave_list_counts(rt_tracer* t, int half, uint32_t* dst, size_t capaci
     const size_t tiles = static_cast<size_t>((k.W + 31u) / 32u) * ((k.rows + 7u) / 8u) * 4u;
     const uint32_t cap = t->params(1).bin_list;
     const size_t n = tiles < capacity_tiles ? tiles : capacity_tiles;
-    HIP_CHECK(hipMemcpy2D(dst, sizeof(uint32_t), t->d_wave_lists[half], static_cast<size_t>(1u + cap) * 112u, sizeof(uint32_t), n, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy2D(dst, sizeof(uint32_t), t->d_wave_lists[half], static_cast<size_t>(1u + cap) * 64u, sizeof(uint32_t), n, hipMemcpyDeviceToHost));
     if (n_tiles) *n_tiles = static_cast<uint32_t>(tiles);
     if (capacity_per_tile) *capacity_per_tile = cap;
   });
