@@ -101,10 +101,9 @@ __global__ __launch_bounds__(256) void wave_lists_kernel(const TraceParams p) {
     float forms[18] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f,
                        0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};     // all-zero forms never reject
     if (fam.usable) {
-      // (two calls that share no live ranges, as in the trace kernel of round 3: the S rules, then the forms)
-      const bool miss3 = tile_misses_triangle<false, false, SlackProduct, true>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z});
-      asm volatile("" : "+v"(A0.x), "+v"(A0.y), "+v"(A0.z), "+v"(A0.w), "+v"(A1.x), "+v"(A1.y), "+v"(A1.z), "+v"(A1.w), "+v"(bz));
-      keep = valid && !miss3 && !tile_misses_triangle<true>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z}, forms);
+      // (one call: no rays are alive here, so the S rules fit beside the forms -- inside the classifying trace kernel of round 3
+      //  they were a call of their own in front of it, for the registers; the verdict is the same conjunction either way)
+      keep = valid && !tile_misses_triangle<true, false, SlackProduct, true>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z}, forms);
     }
     const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
     if (count + static_cast<uint32_t>(__builtin_popcountll(m)) > p.wave_cap) { overflow = true; break; }
