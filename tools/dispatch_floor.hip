@@ -388,9 +388,24 @@ int main(int argc, char** argv) {
     const int NE = 8;
     hipEvent_t ready[NE], rec[NE];
     for (int i = 0; i < NE; ++i) { CK(hipEventCreateWithFlags(&ready[i], hipEventDisableTiming)); CK(hipEventCreateWithFlags(&rec[i], hipEventDisableTiming)); }
-    for (int variant = 0; variant < 5; ++variant) {
+    uint32_t* sig = nullptr;                                            // stream memory operations instead of events (variants 5, 6)
+    int can_wait = 0;
+    (void)hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, 0);
+    if (can_wait && hipExtMallocWithFlags(reinterpret_cast<void**>(&sig), 64, hipMallocSignalMemory) != hipSuccess) { sig = nullptr; (void)hipGetLastError(); }
+    if (sig) CK(hipMemset(sig, 0, 64));
+    uint32_t sig_value = 0;
+    for (int variant = 0; variant < 7; ++variant) {
       const int n = 100;
+      if (variant >= 5 && !sig) { printf("one stream: hipStreamWaitValue32 not available on this device\n"); break; }
       auto step = [&](int i) {
+        if (variant >= 5) {                                             // the builder publishes a counter, the trace stream waits for it
+          launch_mode(0, 4, p, dim3(gx, variant == 6 ? 34 : 4), sl);
+          ++sig_value;
+          CK(hipStreamWriteValue32(sl, sig, sig_value, 0));
+          CK(hipStreamWaitValue32(sa, sig, sig_value, hipStreamWaitValueGte, 0xFFFFFFFFu));
+          launch_mode(2, 4, p, dim3(gx, gy), sa);
+          return;
+        }
         if (variant == 1 || variant == 3 || variant == 4) {
           launch_mode(0, 4, p, dim3(gx, variant == 4 ? 34 : 4), sl);                    // the "builder" (variant 4: a quarter of the grid)
           CK(hipEventRecord(ready[i % NE], sl));
@@ -406,7 +421,8 @@ int main(int argc, char** argv) {
       CK(hipEventRecord(e1, sa));
       CK(hipEventSynchronize(e1));
       float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
-      static const char* vn[5] = {"bare", "cross-stream wait in front of every kernel", "event record behind every kernel", "wait + record", "wait (on a longer builder)"};
+      static const char* vn[7] = {"bare", "cross-stream wait in front of every kernel", "event record behind every kernel", "wait + record", "wait (on a longer builder)",
+                                  "hipStreamWaitValue32 in front of every kernel", "hipStreamWaitValue32 (on a longer builder)"};
       printf("one stream, all-certain frames back to back, %-46s : %7.2f us per step\n", vn[variant], ms / n * 1e3);
     }
   }
