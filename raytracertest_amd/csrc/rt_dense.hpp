@@ -26,6 +26,62 @@
 namespace rtk {
 
 // ------------------------------------------------------------------------------------
+// Can ANY lens sample of ANY pixel of the tile pass all three per-sample forms at once?
+//
+// The trace loop skips a candidate for a ray when min(F1, F2, F3) < 0, F_i = c_i + g_i . dF + n_i . do with the lane's
+// focal offset dF (|dF_k| <= frad_k over the tile) and the sample's lens offset do (|do| <= R: the lens is a disk).  The
+// tile-level rules bound each quantity on its own, so a triangle whose image in lens space -- the intersection of the three
+// half-planes -- lies outside the lens while each half-plane alone still cuts it is kept, evaluated for every sample batch
+// and rejected every time.  With every form taken at its largest over the focal box, C_i = c_i + sum_k |g_ik| frad_k, a sample
+// that passes exists only if the disk meets {x : C_i + n_i . x >= 0 for all i}; by Helly's theorem in the plane that fails
+// iff it fails for the disk and TWO of the half-planes, i.e. iff for some pair the wedge H_i /\ H_j is farther than R from the
+// lens centre: the closest point of a wedge is the centre itself, the foot of the perpendicular on one edge (if the other
+// constraint holds there) or the apex.  A candidate this test drops is one the forms would skip for every sample of every
+// lane: no result changes (the forms' own guarantee, CLASSIFICATION.md), the lists get shorter.  R and the comparison carry
+// 1e-3 relative slack (the roundings of this evaluation and of the loop's fp32 forms are ~1e-6); any NaN keeps the candidate.
+// forms[]: as tile_misses_triangle<FORMS> leaves them (scaled per form by a power of two: the geometry is scale-free).
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ bool lens_can_pass_forms(const float (&forms)[18], const float (&frad)[3], float lens_radius) {
+  float C[3], nx[3], ny[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    C[i] = forms[3 * i] + (__builtin_fabsf(forms[9 + 3 * i]) * frad[0] + __builtin_fabsf(forms[10 + 3 * i]) * frad[1] + __builtin_fabsf(forms[11 + 3 * i]) * frad[2]) * 1.001f;
+    nx[i] = forms[3 * i + 1]; ny[i] = forms[3 * i + 2];
+  }
+  const float R = lens_radius * 1.001f + 1e-30f, R2 = R * R * 1.001f;
+  bool surely_outside = false;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int i = a, j = (a + 1) % 3;
+    if (!(C[i] < 0.0f) && !(C[j] < 0.0f)) continue;                  // the lens centre is inside this wedge (or NaN: keep)
+    // squared distance from the centre to the wedge: the smallest over the boundary points that belong to it
+    float best = __builtin_inff();
+    bool known = false;                                              // some candidate point was valid
+    const float li = nx[i] * nx[i] + ny[i] * ny[i], lj = nx[j] * nx[j] + ny[j] * ny[j];
+    if (C[i] < 0.0f && li > 0.0f) {                                  // foot on edge i: x = -C_i n_i / |n_i|^2
+      const float t = -C[i] / li;
+      const float fx = t * nx[i], fy = t * ny[i];
+      if (C[j] + (nx[j] * fx + ny[j] * fy) >= 0.0f) { best = fminf(best, (C[i] * C[i]) / li); known = true; }
+    }
+    if (C[j] < 0.0f && lj > 0.0f) {
+      const float t = -C[j] / lj;
+      const float fx = t * nx[j], fy = t * ny[j];
+      if (C[i] + (nx[i] * fx + ny[i] * fy) >= 0.0f) { best = fminf(best, (C[j] * C[j]) / lj); known = true; }
+    }
+    const float det = nx[i] * ny[j] - ny[i] * nx[j];
+    if (__builtin_fabsf(det) > 1e-6f * __builtin_amdgcn_sqrtf(li * lj)) {       // the apex: n_i . x = -C_i, n_j . x = -C_j
+      const float vx = (-C[i] * ny[j] + C[j] * ny[i]) / det, vy = (-nx[i] * C[j] + nx[j] * C[i]) / det;
+      best = fminf(best, vx * vx + vy * vy);
+      known = true;
+    } else {
+      known = false;                                                 // (nearly) parallel edges: no verdict from this pair
+    }
+    if (known && best > R2 && best <= 3.0e38f) surely_outside = true;
+  }
+  return !surely_outside;
+}
+
+// ------------------------------------------------------------------------------------
 // wave_lists_kernel: grid = (ceil(W/32), ceil(rows/8)), 256 threads, dynamic LDS = block_list * 4 + 160 bytes.
 // ------------------------------------------------------------------------------------
 template <bool FMA>
@@ -104,6 +160,9 @@ __global__ __launch_bounds__(256) void wave_lists_kernel(const TraceParams p) {
       // (one call: no rays are alive here, so the S rules fit beside the forms -- inside the classifying trace kernel of round 3
       //  they were a call of their own in front of it, for the registers; the verdict is the same conjunction either way)
       keep = valid && !tile_misses_triangle<true, false, SlackProduct, true>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z}, forms);
+#ifndef RT_NO_LENS_JOINT
+      keep = keep && lens_can_pass_forms(forms, fam.frad, fam.A);
+#endif
     }
     const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
     if (count + static_cast<uint32_t>(__builtin_popcountll(m)) > p.wave_cap) { overflow = true; break; }

@@ -236,6 +236,7 @@ __global__ __launch_bounds__(256) void dbg_classify_kernel(const TraceParams p, 
         float ends3[10] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         const bool miss3 = tile_misses_triangle<false, false, SL, true>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z}, nullptr, nullptr, nullptr, ends3);
         keep = !tile_misses_triangle<true, false, SL>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z}, forms, nullptr, nullptr, ends) && !miss3;
+        keep = keep && lens_can_pass_forms(forms, fam.frad, fam.A);      // (wave_lists_kernel's last drop rule: the forms taken jointly)
         ends[8] = ends3[8]; ends[9] = ends3[9];
       }
       r[0] = keep ? 1.0f : 0.0f;
