@@ -91,6 +91,7 @@ class Tally:
     def __init__(self):
         self.regions = self.pairs = self.rays = 0
         self.dropped = self.kept = self.sure = self.sure_tiles = 0
+        self.kept_hit = 0               # kept pairs that some probed ray really hits (how tight the classification is)
         self.bad = {s: {"drop_hit": 0, "drop_win": 0, "sure_miss": 0, "tile_winner": 0} for s in LADDER}
         self.scales = set()             # the scales of the ladder this tally was run at
         self.contain_bad = 0            # (c) at the product's allowances
@@ -105,7 +106,7 @@ class Tally:
         self.examples = []
 
     def merge(self, o):
-        for k in ("regions", "pairs", "rays", "dropped", "kept", "sure", "sure_tiles", "contain_bad", "q_bad", "form_wrong",
+        for k in ("regions", "pairs", "rays", "dropped", "kept", "kept_hit", "sure", "sure_tiles", "contain_bad", "q_bad", "form_wrong",
                   "form_rejects", "form_tests", "nan_pairs", "pair_tiles"):
             setattr(self, k, getattr(self, k) + getattr(o, k))
         for s in LADDER:
@@ -131,7 +132,7 @@ class Tally:
 
     def summary(self):
         return {"regions": self.regions, "tile_triangle_pairs": self.pairs, "rays_per_pair_total": self.rays,
-                "dropped_pairs": self.dropped, "kept_pairs": self.kept, "certainly_hit_pairs": self.sure,
+                "dropped_pairs": self.dropped, "kept_pairs": self.kept, "kept_pairs_hit_by_a_probed_ray": self.kept_hit, "certainly_hit_pairs": self.sure,
                 "certain_winner_tiles": self.sure_tiles, "of_those_by_the_pairwise_bound": self.pair_tiles,
                 "violations_by_scale": {str(s / 1000.0): dict(self.bad[s]) for s in LADDER if s in self.scales},
                 "smallest_passing_scale": self.smallest_passing_scale(),
@@ -168,6 +169,7 @@ def check_region(tag, probe, nohit, rays, recs, hdrs, forms=False, tile_word=Non
     t.kept, t.dropped, t.sure = int(keep1.sum()), int((~keep1).sum()), int(sure1.sum())
     hits, wins = probe["hits"], probe["wins"]
     real_hits = hits - probe["nan_hits"]                     # a hit with t = NaN never wins (Kernels.cuh:84: distance < NaN is false)
+    t.kept_hit = int((keep1 & (hits > 0)).sum())
     t.nan_pairs = int((probe["nan_rays"] > 0).sum())
     for s in LADDER:
         if s not in recs:
