@@ -32,7 +32,7 @@ namespace rtk {
 // focal offset dF (|dF_k| <= frad_k over the tile) and the sample's lens offset do (|do| <= R: the lens is a disk).  The
 // tile-level rules bound each quantity on its own, so a triangle whose image in lens space -- the intersection of the three
 // half-planes -- lies outside the lens while each half-plane alone still cuts it is kept, evaluated for every sample batch
-// and rejected every time.  With every form taken at its largest over the focal box, C_i = c_i + sum_k |g_ik| frad_k, a sample
+// and rejected every time.  With every form taken at its largest over a focal (sub-)box, C_i = c_i + g_i . centre + sum_k |g_ik| r_k, a sample
 // that passes exists only if the disk meets {x : C_i + n_i . x >= 0 for all i}; by Helly's theorem in the plane that fails
 // iff it fails for the disk and TWO of the half-planes, i.e. iff for some pair the wedge H_i /\ H_j is farther than R from the
 // lens centre: the closest point of a wedge is the centre itself, the foot of the perpendicular on one edge (if the other
@@ -41,44 +41,77 @@ namespace rtk {
 // 1e-3 relative slack (the roundings of this evaluation and of the loop's fp32 forms are ~1e-6); any NaN keeps the candidate.
 // forms[]: as tile_misses_triangle<FORMS> leaves them (scaled per form by a power of two: the geometry is scale-free).
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ bool lens_can_pass_forms(const float (&forms)[18], const float (&frad)[3], float lens_radius) {
-  float C[3], nx[3], ny[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    C[i] = forms[3 * i] + (__builtin_fabsf(forms[9 + 3 * i]) * frad[0] + __builtin_fabsf(forms[10 + 3 * i]) * frad[1] + __builtin_fabsf(forms[11 + 3 * i]) * frad[2]) * 1.001f;
-    nx[i] = forms[3 * i + 1]; ny[i] = forms[3 * i + 2];
-  }
-  const float R = lens_radius * 1.001f + 1e-30f, R2 = R * R * 1.001f;
+#ifndef RT_LENS_SPLIT
+#define RT_LENS_SPLIT 2       // the focal box is tested in RT_LENS_SPLIT^2 sub-boxes (its two widest axes split): any partition of
+                              // the box covers every focal point of the tile, and a smaller box fattens the wedges less
+#endif
+// What the wedge tests need of a pair of forms, independent of the (sub-)box: |n_i|^2, |n_j|^2, n_i . n_j, det^2 and whether the
+// edges are too close to parallel for a verdict.  Everything below is division-free: distances are compared as
+// (numerator)^2 > R^2 (denominator)^2.
+struct WedgePair { float li, lj, dij, det2; bool par; };
+__device__ __forceinline__ WedgePair wedge_pair(float nxi, float nyi, float nxj, float nyj) {
+  WedgePair w;
+  w.li = nxi * nxi + nyi * nyi; w.lj = nxj * nxj + nyj * nyj; w.dij = nxi * nxj + nyi * nyj;
+  const float det = nxi * nyj - nyi * nxj;
+  w.det2 = det * det;
+  w.par = !(w.det2 > 1e-12f * (w.li * w.lj));                       // (NaN: no verdict)
+  return w;
+}
+// one (sub-)box: form i at its largest over it is C[i]; true = the disk of radius^2 R2 may meet all three half-planes
+__device__ __forceinline__ bool lens_meets_wedges(const float (&C)[3], const float (&nx)[3], const float (&ny)[3], const WedgePair (&wp)[3], float R2) {
   bool surely_outside = false;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     const int i = a, j = (a + 1) % 3;
-    if (!(C[i] < 0.0f) && !(C[j] < 0.0f)) continue;                  // the lens centre is inside this wedge (or NaN: keep)
-    // squared distance from the centre to the wedge: the smallest over the boundary points that belong to it
-    float best = __builtin_inff();
-    bool known = false;                                              // some candidate point was valid
-    const float li = nx[i] * nx[i] + ny[i] * ny[i], lj = nx[j] * nx[j] + ny[j] * ny[j];
-    if (C[i] < 0.0f && li > 0.0f) {                                  // foot on edge i: x = -C_i n_i / |n_i|^2
-      const float t = -C[i] / li;
-      const float fx = t * nx[i], fy = t * ny[i];
-      if (C[j] + (nx[j] * fx + ny[j] * fy) >= 0.0f) { best = fminf(best, (C[i] * C[i]) / li); known = true; }
-    }
-    if (C[j] < 0.0f && lj > 0.0f) {
-      const float t = -C[j] / lj;
-      const float fx = t * nx[j], fy = t * ny[j];
-      if (C[i] + (nx[i] * fx + ny[i] * fy) >= 0.0f) { best = fminf(best, (C[j] * C[j]) / lj); known = true; }
-    }
-    const float det = nx[i] * ny[j] - ny[i] * nx[j];
-    if (__builtin_fabsf(det) > 1e-6f * __builtin_amdgcn_sqrtf(li * lj)) {       // the apex: n_i . x = -C_i, n_j . x = -C_j
-      const float vx = (-C[i] * ny[j] + C[j] * ny[i]) / det, vy = (-nx[i] * C[j] + nx[j] * C[i]) / det;
-      best = fminf(best, vx * vx + vy * vy);
-      known = true;
-    } else {
-      known = false;                                                 // (nearly) parallel edges: no verdict from this pair
-    }
-    if (known && best > R2 && best <= 3.0e38f) surely_outside = true;
+    const WedgePair& w = wp[a];
+    const float Ci = C[i], Cj = C[j];
+    const bool centre_inside = !(Ci < 0.0f) && !(Cj < 0.0f);       // (or NaN: keep)
+    // the closest point of the wedge H_i /\ H_j to the lens centre is the foot of the perpendicular on edge i (if C_i < 0 and the
+    // foot satisfies j: C_j |n_i|^2 - C_i n_i.n_j >= 0), the foot on edge j, or the apex; the wedge is outside the disk when every
+    // one of those that belongs to it is: C_i^2 > R^2 |n_i|^2, |C_i n_j - C_j n_i|^2 > R^2 det^2
+    const bool foot_i = (Ci < 0.0f) && (w.li > 0.0f) && (Cj * w.li - Ci * w.dij >= 0.0f);
+    const bool foot_j = (Cj < 0.0f) && (w.lj > 0.0f) && (Ci * w.lj - Cj * w.dij >= 0.0f);
+    const bool far_i = Ci * Ci > R2 * w.li, far_j = Cj * Cj > R2 * w.lj;
+    const float wx = Ci * nx[j] - Cj * nx[i], wy = Ci * ny[j] - Cj * ny[i];
+    const float apex2 = wx * wx + wy * wy;
+    const bool far_apex = (apex2 > R2 * w.det2) && (apex2 <= 3.0e38f);
+    const bool outside = !centre_inside && !w.par && far_apex && (!foot_i || far_i) && (!foot_j || far_j);
+    surely_outside = surely_outside || outside;
   }
   return !surely_outside;
+}
+
+__device__ __forceinline__ bool lens_can_pass_forms(const float (&forms)[18], const float (&frad)[3], float lens_radius) {
+  float nx[3], ny[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { nx[i] = forms[3 * i + 1]; ny[i] = forms[3 * i + 2]; }
+  WedgePair wp[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) wp[a] = wedge_pair(nx[a], ny[a], nx[(a + 1) % 3], ny[(a + 1) % 3]);
+  const float R = lens_radius * 1.001f + 1e-30f, R2 = R * R * 1.001f;
+  // the two widest axes of the focal box are split, the third keeps its radius (wave-uniform choice)
+  const int narrow = (frad[0] <= frad[1] && frad[0] <= frad[2]) ? 0 : (frad[1] <= frad[2] ? 1 : 2);
+  const int ua = narrow == 0 ? 1 : 0, ub = narrow == 2 ? 1 : 2;
+  constexpr int S = RT_LENS_SPLIT;
+  const float ha = frad[ua] / S, hb = frad[ub] / S;                  // sub-box radii (1.001 below covers the roundings of the centres)
+  float c0[3], ga[3], gb[3], spread[3];                              // per form: constant, gradient along the split axes, radius term of a sub-box
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    ga[i] = forms[9 + 3 * i + ua]; gb[i] = forms[9 + 3 * i + ub];
+    c0[i] = forms[3 * i];
+    spread[i] = (__builtin_fabsf(ga[i]) * ha + __builtin_fabsf(gb[i]) * hb + __builtin_fabsf(forms[9 + 3 * i + narrow]) * frad[narrow]) * 1.001f;
+  }
+  bool any = false;
+  for (int qa = 0; qa < S; ++qa) {
+    for (int qb = 0; qb < S; ++qb) {
+      const float ca = (2.0f * qa + 1.0f - S) * ha, cb = (2.0f * qb + 1.0f - S) * hb;       // sub-box centre relative to the box centre
+      float C[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) C[i] = (c0[i] + (ga[i] * ca + gb[i] * cb)) + spread[i];
+      any = any || lens_meets_wedges(C, nx, ny, wp, R2);
+    }
+  }
+  return any;
 }
 
 // ------------------------------------------------------------------------------------
