@@ -45,37 +45,31 @@ namespace rtk {
 #define RT_LENS_SPLIT 2       // the focal box is tested in RT_LENS_SPLIT^2 sub-boxes (its two widest axes split): any partition of
                               // the box covers every focal point of the tile, and a smaller box fattens the wedges less
 #endif
-// What the wedge tests need of a pair of forms, independent of the (sub-)box: |n_i|^2, |n_j|^2, n_i . n_j, det^2 and whether the
-// edges are too close to parallel for a verdict.  Everything below is division-free: distances are compared as
-// (numerator)^2 > R^2 (denominator)^2.
-struct WedgePair { float li, lj, dij, det2; bool par; };
-__device__ __forceinline__ WedgePair wedge_pair(float nxi, float nyi, float nxj, float nyj) {
-  WedgePair w;
-  w.li = nxi * nxi + nyi * nyi; w.lj = nxj * nxj + nyj * nyj; w.dij = nxi * nxj + nyi * nyj;
-  const float det = nxi * nyj - nyi * nxj;
-  w.det2 = det * det;
-  w.par = !(w.det2 > 1e-12f * (w.li * w.lj));                       // (NaN: no verdict)
-  return w;
-}
-// one (sub-)box: form i at its largest over it is C[i]; true = the disk of radius^2 R2 may meet all three half-planes
-__device__ __forceinline__ bool lens_meets_wedges(const float (&C)[3], const float (&nx)[3], const float (&ny)[3], const WedgePair (&wp)[3], float R2) {
+// one (sub-)box: form i at its largest over it is C[i]; true = the disk of radius^2 R2 may meet all three half-planes.
+// Division-free: distances are compared as (numerator)^2 > R^2 (denominator)^2.  (The pair constants |n_i|^2, n_i . n_j, det^2
+// are recomputed per sub-box; hoisting them buys nothing.  What did push the build kernel into scratch -- 68 bytes per lane,
+// 340 MB of HBM traffic per C4 launch -- was forms[] indexed by a run-time axis in lens_can_pass_forms: see the selects there.)
+__device__ __forceinline__ bool lens_meets_wedges(const float (&C)[3], const float (&nx)[3], const float (&ny)[3], float R2) {
   bool surely_outside = false;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     const int i = a, j = (a + 1) % 3;
-    const WedgePair& w = wp[a];
+    const float li = nx[i] * nx[i] + ny[i] * ny[i], lj = nx[j] * nx[j] + ny[j] * ny[j], dij = nx[i] * nx[j] + ny[i] * ny[j];
+    const float det = nx[i] * ny[j] - ny[i] * nx[j];
+    const float det2 = det * det;
+    const bool par = !(det2 > 1e-12f * (li * lj));                  // edges too close to parallel (or NaN): no verdict from this pair
     const float Ci = C[i], Cj = C[j];
     const bool centre_inside = !(Ci < 0.0f) && !(Cj < 0.0f);       // (or NaN: keep)
     // the closest point of the wedge H_i /\ H_j to the lens centre is the foot of the perpendicular on edge i (if C_i < 0 and the
     // foot satisfies j: C_j |n_i|^2 - C_i n_i.n_j >= 0), the foot on edge j, or the apex; the wedge is outside the disk when every
     // one of those that belongs to it is: C_i^2 > R^2 |n_i|^2, |C_i n_j - C_j n_i|^2 > R^2 det^2
-    const bool foot_i = (Ci < 0.0f) && (w.li > 0.0f) && (Cj * w.li - Ci * w.dij >= 0.0f);
-    const bool foot_j = (Cj < 0.0f) && (w.lj > 0.0f) && (Ci * w.lj - Cj * w.dij >= 0.0f);
-    const bool far_i = Ci * Ci > R2 * w.li, far_j = Cj * Cj > R2 * w.lj;
+    const bool foot_i = (Ci < 0.0f) && (li > 0.0f) && (Cj * li - Ci * dij >= 0.0f);
+    const bool foot_j = (Cj < 0.0f) && (lj > 0.0f) && (Ci * lj - Cj * dij >= 0.0f);
+    const bool far_i = Ci * Ci > R2 * li, far_j = Cj * Cj > R2 * lj;
     const float wx = Ci * nx[j] - Cj * nx[i], wy = Ci * ny[j] - Cj * ny[i];
     const float apex2 = wx * wx + wy * wy;
-    const bool far_apex = (apex2 > R2 * w.det2) && (apex2 <= 3.0e38f);
-    const bool outside = !centre_inside && !w.par && far_apex && (!foot_i || far_i) && (!foot_j || far_j);
+    const bool far_apex = (apex2 > R2 * det2) && (apex2 <= 3.0e38f);
+    const bool outside = !centre_inside && !par && far_apex && (!foot_i || far_i) && (!foot_j || far_j);
     surely_outside = surely_outside || outside;
   }
   return !surely_outside;
@@ -85,21 +79,21 @@ __device__ __forceinline__ bool lens_can_pass_forms(const float (&forms)[18], co
   float nx[3], ny[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) { nx[i] = forms[3 * i + 1]; ny[i] = forms[3 * i + 2]; }
-  WedgePair wp[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) wp[a] = wedge_pair(nx[a], ny[a], nx[(a + 1) % 3], ny[(a + 1) % 3]);
   const float R = lens_radius * 1.001f + 1e-30f, R2 = R * R * 1.001f;
   // the two widest axes of the focal box are split, the third keeps its radius (wave-uniform choice)
-  const int narrow = (frad[0] <= frad[1] && frad[0] <= frad[2]) ? 0 : (frad[1] <= frad[2] ? 1 : 2);
-  const int ua = narrow == 0 ? 1 : 0, ub = narrow == 2 ? 1 : 2;
+  // (selected with compares, not indexed: a register array indexed by a run-time value lives in scratch)
+  const bool n0 = frad[0] <= frad[1] && frad[0] <= frad[2], n1 = !n0 && frad[1] <= frad[2];      // the narrow axis: 0, 1, else 2
   constexpr int S = RT_LENS_SPLIT;
-  const float ha = frad[ua] / S, hb = frad[ub] / S;                  // sub-box radii (1.001 below covers the roundings of the centres)
+  const float ra = n0 ? frad[1] : frad[0], rb = (n0 || n1) ? frad[2] : frad[1], rn = n0 ? frad[0] : n1 ? frad[1] : frad[2];
+  const float ha = ra / S, hb = rb / S;                              // sub-box radii (1.001 below covers the roundings of the centres)
   float c0[3], ga[3], gb[3], spread[3];                              // per form: constant, gradient along the split axes, radius term of a sub-box
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    ga[i] = forms[9 + 3 * i + ua]; gb[i] = forms[9 + 3 * i + ub];
+    const float g0 = forms[9 + 3 * i], g1 = forms[10 + 3 * i], g2 = forms[11 + 3 * i];
+    ga[i] = n0 ? g1 : g0; gb[i] = (n0 || n1) ? g2 : g1;
+    const float gn = n0 ? g0 : n1 ? g1 : g2;
     c0[i] = forms[3 * i];
-    spread[i] = (__builtin_fabsf(ga[i]) * ha + __builtin_fabsf(gb[i]) * hb + __builtin_fabsf(forms[9 + 3 * i + narrow]) * frad[narrow]) * 1.001f;
+    spread[i] = (__builtin_fabsf(ga[i]) * ha + __builtin_fabsf(gb[i]) * hb + __builtin_fabsf(gn) * rn) * 1.001f;
   }
   bool any = false;
   for (int qa = 0; qa < S; ++qa) {
@@ -108,7 +102,7 @@ __device__ __forceinline__ bool lens_can_pass_forms(const float (&forms)[18], co
       float C[3];
 #pragma unroll
       for (int i = 0; i < 3; ++i) C[i] = (c0[i] + (ga[i] * ca + gb[i] * cb)) + spread[i];
-      any = any || lens_meets_wedges(C, nx, ny, wp, R2);
+      any = any || lens_meets_wedges(C, nx, ny, R2);
     }
   }
   return any;
