@@ -260,3 +260,12 @@ def test_dense_list_overflow_falls_back_to_the_macro_list(rt):
         if n == 20000:
             assert over.mean() > 0.9                       # the fallback is what this frame ran
         g.close(); ref.close()
+
+
+def test_dense_launch_machinery_soak(rt):
+    """tools/soak_dense.py: random Trace / TraceEnqueue / Launch with changing sample counts and update cadences, camera swings,
+    lens changes, scene swaps between dense, mid-size and small scenes, Resize and list reuse on / off against the same operations
+    on a full-scan tracer -- every phase bit for bit (the keys of the macro and per-wave lists, their reuse and rebuilds)."""
+    import subprocess, sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_dense.py"), "50", "11"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "soak_dense ok: 50 phases" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
