@@ -3,7 +3,7 @@
 (small scenes) or sampled regions of all three levels (large scenes, with the per-sample forms), against the reference's own
 per-ray arithmetic (tests/classification_check.py).  Prints and writes the margin record: violations per allowance scale,
 the smallest passing scale, and how far the reference's values reach into the allowances ("needed scale").
-Usage: classification_margin.py [N] [seed] [out.json]"""
+Usage: classification_margin.py [N] [seed] [out.json] [share of the adversarial configurations that are dense scenes, default 0.04]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -18,6 +18,7 @@ from adversarial import adversarial_config, cover_config
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 31
 out_path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "gpurun_out", "classification_margin.json")
+large_share = float(sys.argv[4]) if len(sys.argv) > 4 else 0.04
 rng = np.random.default_rng(seed)
 lens = cc.lens_samples(orc, seed=seed, pixel_index=3)
 small = np.concatenate([lens[:1], lens[1:113:2], lens[-8:]])
@@ -26,7 +27,7 @@ tallies = {"small_scenes": cc.Tally(), "cover_scenes": cc.Tally(), "small_scenes
 t0 = time.time()
 for it in range(N + N // 2):
     kind = "adv" if it < N else "cover"
-    large = kind == "adv" and rng.uniform() < 0.04
+    large = kind == "adv" and rng.uniform() < large_share
     c = cover_config(rng) if kind == "cover" else adversarial_config(rng, large=large)
     n = c["tris"].shape[0]
     g = R.RayTracer((c["W"], c["H"]), (0, 0, 0), c["cam"]["angles"], c["cam"]["fov"], c["cam"]["focal"], c["cam"]["aperture"],
