@@ -178,7 +178,7 @@ int  rt_tracer_set_list_reuse(rt_tracer* t, int across_traces);
  * (rt_tracer_stream) and keeps the buffer alive. */
 int  rt_tracer_set_image_mirror(rt_tracer* t, void* device_visible_image);
 /* Sum of the durations of the SAMPLED trace launches (HIP events on the tracer's stream, around
- * every 4th launch and every launch the caller waits for: an event pair costs ~5 us per launch) and
+ * every 16th launch and every launch the caller waits for: an event pair costs ~5 us per launch) and
  * their number since the last reset; total_ms / launches = mean launch duration -- of a split launch
  * (see rt_tracer_stream_b) the upper half-frame kernel's, whose execution overlaps the lower half's.  reset_after != 0
  * clears both and makes the next launch a sampled one. */

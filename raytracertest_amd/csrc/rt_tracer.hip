@@ -140,6 +140,9 @@ struct Camera {
   }
 };
 
+#ifndef RT_EVENT_STRIDE
+#define RT_EVENT_STRIDE 16        // every 16th launch carries timing events (an event record costs its stream 1.4 us: stride 4 -> 16 bought 1.8 % of a C3 step)
+#endif
 #ifndef RT_PRETEST_LIST
 #define RT_PRETEST_LIST 84u      // per-wave list capacity of the dense-scene kernels with forms: 4 x 84 x 116 bytes = 38 KiB of LDS per block (C4's fullest tile: 48)
 #endif
@@ -859,7 +862,7 @@ struct rt_tracer {
   // Macro level of the classification (scenes that do not fit the per-wave list): sizes the
   // lists, points the launch at them and runs macro_bin_kernel on the stream ahead of the trace
   // launch.  Every launch re-bins (the camera may have changed; the pass costs N x macro tiles tests).
-  static constexpr uint32_t kEventStride = 4;     // every 4th launch carries timing events (an event record is a packet the next kernel queues behind)
+  static constexpr uint32_t kEventStride = RT_EVENT_STRIDE;     // every n-th launch carries timing events (an event record is a packet the next kernel queues behind)
   std::atomic<uint32_t> launch_counter{0};
   uint32_t* d_macro_lists[2] = {nullptr, nullptr};   // one per half of a split launch
   size_t macro_lists_words[2] = {0, 0};

@@ -198,8 +198,8 @@ def test_group_info_and_gather_only_through_rccl_on_one_rank(rt, orc, monkeypatc
     from raytracertest_amd import scenes
     h.UploadScene(scenes.cornell32())
     h.KernelTime()
-    for _ in range(8):
-        h.TraceEnqueue(1, 8)                      # 300 rows: split launches
+    for _ in range(20):
+        h.TraceEnqueue(1, 8)                      # 300 rows: split launches (every 16th launch carries timing events: two samples)
     h.Sync()
     span_ms, n1 = h.LaunchTime(reset=False)
     k_ms, n2 = h.KernelTime()
