@@ -109,45 +109,72 @@ __device__ __forceinline__ bool lens_can_pass_forms(const float (&forms)[18], co
 }
 
 // ------------------------------------------------------------------------------------
-// wave_lists_kernel: grid = (ceil(W/32), ceil(rows/8)), 256 threads, dynamic LDS = block_list * 4 + 160 bytes.
+// wave_lists_kernel: one WAVE per block of 32 x 8 pixels (its four 8 x 8 tiles), four blocks per workgroup; no barrier.
+// grid = ceil(blocks / 4) workgroups of 256 threads, dynamic LDS = 4 waves x block_list x 4 bytes.
+//
+// (Until r04_g one wave per TILE, four waves sharing the block list through LDS: every wave paid a whole pass of the forms
+// -- ~850 instructions on 64 lanes -- for the ~12 entries of its block list, 1 500 instructions per tile, 8 % of a C4
+// step's instructions and most of what a rebuilt step costs over one with the lists kept.)  Here
+//   1. the wave visits its four tiles in turn, lane = pixel, for their focal boxes (focal_bounds: the same calls, the same
+//      values as the tile's own wave computed), the block's box is their union;
+//   2. block level, lane = entry of the macro tile's list: the union family, survivors ascending into this wave's LDS list;
+//   3. tile level, lane = tile * 16 + entry: sixteen entries of the block list per pass against each of the four tiles' OWN
+//      families (per lane: selected from the four boxes), third-edge rules + forms + the joint lens rule, compaction per
+//      16-lane group, survivors straight into the tile's records.
+// The verdict functions, their inputs and the order of the survivors are those of the one-wave-per-tile build: same lists.
 // ------------------------------------------------------------------------------------
 template <bool FMA>
-__global__ __launch_bounds__(256) void wave_lists_kernel(const TraceParams p) {
+__global__ __launch_bounds__(256, 4) void wave_lists_kernel(const TraceParams p) {
   extern __shared__ float4 s_mem[];
   // The build runs in front of its half's trace kernel and beside the OTHER half's, whose long-lived waves would win every
   // arbitration against it: at the highest wave priority the 0.3 ms chain of dependent loads and classifications shortens
   // (C4 3.24 -> 3.10 ms per step; the trace waves lose what the build gains, the step's critical path is what shrinks).
   __builtin_amdgcn_s_setprio(3);
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const uint32_t px = blockIdx.x * 32u + wave * 8u + (lane & 7u), ly = blockIdx.y * 8u + (lane >> 3);
-  const bool inside = px < p.W && ly < p.rows;
-  V3 po, pd;
-  pinhole<FMA>(p, inside ? px : 0u, p.row0 + (inside ? ly : 0u), po, pd);
-  const V3 focal = focal_point<FMA>(p, pd);
+  const uint32_t gxb = (p.W + 31u) / 32u, gyb = (p.rows + 7u) / 8u;
+  const uint32_t blk = blockIdx.x * 4u + wave;
+  if (blk >= gxb * gyb) return;                                      // wave-uniform; no barrier below
+  const uint32_t bx = blk % gxb, by = blk / gxb;
+
+  // ---- 1. the four tiles' focal boxes (wave-uniform values) and their union
+  FocalBounds wb[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const uint32_t px = bx * 32u + static_cast<uint32_t>(t) * 8u + (lane & 7u), ly = by * 8u + (lane >> 3);
+    const bool inside = px < p.W && ly < p.rows;
+    V3 po, pd;
+    pinhole<FMA>(p, inside ? px : 0u, p.row0 + (inside ? ly : 0u), po, pd);
+    wb[t] = focal_bounds(p, focal_point<FMA>(p, pd), inside);
+  }
+  FocalBounds bb;
+  bb.ok = wb[0].ok && wb[1].ok && wb[2].ok && wb[3].ok;
+  bb.any = wb[0].any || wb[1].any || wb[2].any || wb[3].any;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    bb.lo[i] = fminf(fminf(fminf(fminf(FLT_MAX, wb[0].lo[i]), wb[1].lo[i]), wb[2].lo[i]), wb[3].lo[i]);       // (block_focal_union's order)
+    bb.hi[i] = fmaxf(fmaxf(fmaxf(fmaxf(-FLT_MAX, wb[0].hi[i]), wb[1].hi[i]), wb[2].hi[i]), wb[3].hi[i]);
+  }
 
   const uint32_t Lb = p.block_list;
-  uint32_t* const bI = reinterpret_cast<uint32_t*>(s_mem);
-  uint32_t* const bcnt = bI + Lb;
-  float* const bbox = reinterpret_cast<float*>(bcnt + 8);
+  uint32_t* const bI = reinterpret_cast<uint32_t*>(s_mem) + static_cast<size_t>(wave) * Lb;
   uint32_t src_count = p.n_tris;
   bool src_is_block_list = false;
   const uint32_t* mI = nullptr;
   if (p.macro_lists != nullptr) {
-    const uint32_t mt = (blockIdx.y * 8u / p.macro_h) * p.macro_nx + (blockIdx.x * 32u / p.macro_w);
+    const uint32_t mt = (by * 8u / p.macro_h) * p.macro_nx + (bx * 32u / p.macro_w);
     const uint32_t* const ml = p.macro_lists + static_cast<size_t>(mt) * (p.macro_cap + 1u);
     const uint32_t mc = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ml[0])));
     if (mc != 0xFFFFFFFFu) { mI = ml + 1; src_count = mc; }
   }
   const uint32_t n_src = src_count;
-  const FocalBounds wb = focal_bounds(p, focal, inside);
-  const TileFamily fam = make_family(p, wb);
-  if (Lb != 0u) {                                                    // block level: the union of the four tiles' families
-    const FocalBounds bb = block_focal_union(wb, bbox, wave, lane);
+
+  // ---- 2. block level, lane = entry of the macro tile's list
+  if (Lb != 0u) {
     const TileFamily bfam = make_family(p, bb);
-    uint32_t total = 0, step = 0;
+    uint32_t total = 0;
     bool overflow = false;
-    for (uint32_t base = 0; base < n_src; base += 256u, ++step) {
-      const uint32_t e = base + threadIdx.x;
+    for (uint32_t base = 0; base < n_src; base += 64u) {
+      const uint32_t e = base + lane;
       const bool valid = e < n_src;
       const uint32_t ei = valid ? e : (n_src - 1u);
       const uint32_t tri = mI != nullptr ? mI[ei] : ei;
@@ -157,47 +184,57 @@ __global__ __launch_bounds__(256) void wave_lists_kernel(const TraceParams p) {
       if (bfam.usable)
         keep = valid && !tile_misses_triangle<false, false, SlackProduct, true>(bfam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z});
       const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
-      uint32_t* const slot = bcnt + (step & 1u) * 4u;                // double-buffered: one barrier per step
-      if (lane == 0u) slot[wave] = static_cast<uint32_t>(__builtin_popcountll(m));
-      __syncthreads();
-      const uint32_t c0 = slot[0], c1 = slot[1], c2 = slot[2], c3 = slot[3];
-      const uint32_t before = (wave > 0u ? c0 : 0u) + (wave > 1u ? c1 : 0u) + (wave > 2u ? c2 : 0u);
-      const uint32_t step_total = c0 + c1 + c2 + c3;
-      if (total + step_total > Lb) { overflow = true; break; }       // block-uniform
-      const uint32_t pos = total + before + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
-      if (keep) bI[pos] = tri;                                       // ascending order across waves and steps
-      total += step_total;
+      const uint32_t kept = static_cast<uint32_t>(__builtin_popcountll(m));
+      if (total + kept > Lb) { overflow = true; break; }             // wave-uniform: the tiles walk the macro tile's list instead
+      const uint32_t pos = total + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+      if (keep) bI[pos] = tri;                                       // ascending
+      total += kept;
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");            // this wave's ds_writes before its ds_reads
+    __builtin_amdgcn_wave_barrier();
     if (!overflow) { src_count = total; src_is_block_list = true; }
   }
 
-  // ---- wave level, lane = candidate of the block list: third-edge rules, then the forms; survivors straight into the tile's records
-  const size_t slot = (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 4u + wave;
+  // ---- 3. tile level, lane = tile * 16 + entry
+  const uint32_t t4 = lane >> 4, c = lane & 15u;
+  FocalBounds mine = wb[0];                                          // selected with compares, not indexed (scratch otherwise)
+#pragma unroll
+  for (int t = 1; t < 4; ++t) {
+    const bool is = t4 == static_cast<uint32_t>(t);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { mine.lo[i] = is ? wb[t].lo[i] : mine.lo[i]; mine.hi[i] = is ? wb[t].hi[i] : mine.hi[i]; }
+    mine.ok = is ? wb[t].ok : mine.ok;
+    mine.any = is ? wb[t].any : mine.any;
+  }
+  const TileFamily fam = make_family(p, mine);
+  const size_t slot = (static_cast<size_t>(by) * gxb + bx) * 4u + t4;
   uint32_t* const out = p.wave_lists + slot * (1u + p.wave_cap) * kWaveRec;
-  uint32_t count = 0;
+  const uint32_t gsh = lane & 48u;                                   // first lane of this tile's 16-lane group
+  uint32_t count = 0;                                                // (the same in the 16 lanes of a group)
   bool overflow = false;
-  for (uint32_t base = 0; base < src_count; base += 64u) {           // (wave-uniform trip count)
-    const uint32_t e = base + lane;
-    const bool valid = e < src_count;
-    const uint32_t ei = valid ? e : (src_count - 1u);
+  for (uint32_t base = 0; base < src_count; base += 16u) {            // (wave-uniform trip count)
+    const uint32_t e = base + c;
+    const bool valid = e < src_count && !overflow;
+    const uint32_t ei = e < src_count ? e : (src_count - 1u);
     const uint32_t tri = src_is_block_list ? bI[ei] : (mI != nullptr ? mI[ei] : ei);
-    float4 A0 = p.tri_a[2u * tri], A1 = p.tri_a[2u * tri + 1u];
-    float bz = p.tri_b[tri];
+    const float4 A0 = p.tri_a[2u * tri], A1 = p.tri_a[2u * tri + 1u];
+    const float bz = p.tri_b[tri];
     bool keep = valid;
     float forms[18] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f,
                        0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};     // all-zero forms never reject
     if (fam.usable) {
       // (one call: no rays are alive here, so the S rules fit beside the forms -- inside the classifying trace kernel of round 3
       //  they were a call of their own in front of it, for the registers; the verdict is the same conjunction either way)
-      keep = valid && !tile_misses_triangle<true, false, SlackProduct, true>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z}, forms);
+      const bool miss = tile_misses_triangle<true, false, SlackProduct, true>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z}, forms);
+      keep = valid && !miss;
 #ifndef RT_NO_LENS_JOINT
       keep = keep && lens_can_pass_forms(forms, fam.frad, fam.A);
 #endif
     }
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
-    if (count + static_cast<uint32_t>(__builtin_popcountll(m)) > p.wave_cap) { overflow = true; break; }
-    const uint32_t pos = count + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+    const uint32_t gm = static_cast<uint32_t>(__builtin_amdgcn_ballot_w64(keep) >> gsh) & 0xFFFFu;
+    const uint32_t kept = static_cast<uint32_t>(__builtin_popcount(gm));
+    if (count + kept > p.wave_cap) { overflow = true; keep = false; }   // this tile only: its header says so, its records are void
+    const uint32_t pos = count + static_cast<uint32_t>(__builtin_popcount(gm & ((1u << c) - 1u)));
     if (keep) {                                                      // ascending order is preserved
       auto pk = [&](float hi, float lo) {                            // two fp16 (the values are fp16-exact already) in one word
         const uint32_t h = __builtin_bit_cast(uint16_t, static_cast<_Float16>(hi)), l = __builtin_bit_cast(uint16_t, static_cast<_Float16>(lo));
@@ -209,9 +246,9 @@ __global__ __launch_bounds__(256) void wave_lists_kernel(const TraceParams p) {
       r[2] = make_float4(forms[8], pk(forms[9], forms[10]), pk(forms[11], forms[12]), pk(forms[13], forms[14]));
       r[3] = make_float4(pk(forms[15], forms[16]), pk(forms[17], 0.0f), __builtin_bit_cast(float, tri), 0.0f);
     }
-    count += static_cast<uint32_t>(__builtin_popcountll(m));
+    if (!overflow) count += kept;
   }
-  if (lane == 0u) {
+  if (c == 0u) {
     reinterpret_cast<float4*>(out)[0] = make_float4(__builtin_bit_cast(float, overflow ? kWaveOverflow : count), fam.fc[0], fam.fc[1], fam.fc[2]);
   }
 }

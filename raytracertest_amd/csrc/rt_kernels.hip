@@ -378,8 +378,8 @@ static void launch_dense(const TraceParams& p, int K, dim3 grid, size_t lds, hip
 
 hipError_t launch_wave_lists(const TraceParams& p, bool fma, hipStream_t st) {
   if (p.wave_lists == nullptr || p.rows == 0u || p.W == 0u) return hipSuccess;
-  const dim3 grid(cdiv(p.W, 32), cdiv(p.rows, 8));
-  const size_t lds = static_cast<size_t>(p.block_list) * 4u + 160u;
+  const dim3 grid(cdiv(cdiv(p.W, 32) * cdiv(p.rows, 8), 4));           // one wave per block of 32 x 8 pixels
+  const size_t lds = static_cast<size_t>(p.block_list) * 4u * 4u;
   if (fma) hipLaunchKernelGGL(wave_lists_kernel<true>, grid, dim3(256), lds, st, p);
   else hipLaunchKernelGGL(wave_lists_kernel<false>, grid, dim3(256), lds, st, p);
   return hipGetLastError();
