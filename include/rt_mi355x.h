@@ -47,6 +47,8 @@ extern "C" {
 
 #define RT_FLAG_NO_MACRO_BINS 16u /* disable the macro-tile level of the classification (large scenes): every block
                                   pre-culls the whole triangle list (debug / parity tests / A-B) */
+#define RT_FLAG_NO_SUPER_BINS 64u /* dense scenes: the macro tiles scan the whole triangle list instead of their super tile's
+                                  (debug / parity tests / A-B; the result is the same) */
 #define RT_FLAG_NO_SURE_HIT 32u /* small scenes: run the intersection tests also on tiles whose candidate list is one triangle that
                                   every ray of the tile certainly hits (debug / parity tests / A-B; the result is the same) */
 #define RT_FLAG_SMOOTH_NORMALS 8u /* shading extension for scenes uploaded with rt_tracer_upload_scene_edges: the

@@ -23,6 +23,7 @@ FLAG_NO_BINNING = 2
 FLAG_NEAREST_HIT = 4
 FLAG_SMOOTH_NORMALS = 8
 FLAG_NO_MACRO_BINS = 16
+FLAG_NO_SUPER_BINS = 64
 FLAG_NO_SURE_HIT = 32
 BUF_RENDER, BUF_COUNTS, BUF_IMAGE, BUF_RNG, BUF_FRAME = 0, 1, 2, 3, 4
 GROUP_ID_BYTES = 128
@@ -234,7 +235,7 @@ class RayTracer:
 
     def __init__(self, imageSize, cameraPosition=(0.0, 0.0, 0.0), cameraAngles=(0.0, 0.0), fov=70.0,
                  focalLength=10.0, aperture=4.0, *, seed=None, device=0, math_mode=MATH_FMA,
-                 full_height=0, row_begin=0, no_filter=False, no_binning=False, nearest_hit=False, smooth_normals=False, no_macro_bins=False, samples_in_flight=0,
+                 full_height=0, row_begin=0, no_filter=False, no_binning=False, nearest_hit=False, smooth_normals=False, no_macro_bins=False, no_super_bins=False, samples_in_flight=0,
                  lds_chunk=0, bin_list=0, devices=None, no_sure_hit=False, transport="rccl"):
         """devices: a list of HIP device ordinals, one per row band -> the frame is sharded over them inside
         this process (rt_tracer_create_multi; ordinals may repeat); None -> one tracer on `device`."""
@@ -251,7 +252,7 @@ class RayTracer:
         opt.seed = 0 if seed is None else int(seed)
         opt.math_mode = math_mode
         opt.flags = ((FLAG_NO_FILTER if no_filter else 0) | (FLAG_NO_BINNING if no_binning else 0) |
-                     (FLAG_NEAREST_HIT if nearest_hit else 0) | (FLAG_SMOOTH_NORMALS if smooth_normals else 0) | (FLAG_NO_MACRO_BINS if no_macro_bins else 0) |
+                     (FLAG_NEAREST_HIT if nearest_hit else 0) | (FLAG_SMOOTH_NORMALS if smooth_normals else 0) | (FLAG_NO_MACRO_BINS if no_macro_bins else 0) | (FLAG_NO_SUPER_BINS if no_super_bins else 0) |
                      (FLAG_NO_SURE_HIT if no_sure_hit else 0))
         opt.samples_in_flight, opt.lds_chunk, opt.bin_list = samples_in_flight, lds_chunk, bin_list
         opt.transport = {"rccl": TRANSPORT_RCCL, "peer": TRANSPORT_PEER}[transport]

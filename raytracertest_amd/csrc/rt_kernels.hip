@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void dbg_focal_boxes_kernel(const TraceParams 
 // One block per REGION of the band -- level 0: the 8x8 wave tile at (x0, y0), bounded exactly as a trace wave bounds
 // it (focal_bounds: corner path for full tiles); level 1: the 32x8 block at (x0, y0), the union of its four wave tiles
 // (block_focal_union, the trace kernel's block-level pre-cull); level 2: the macro tile of p.macro_w x p.macro_h pixels
-// at (x0, y0) (macro_focal_bounds, macro_bin_kernel) -- and for EVERY triangle of the scene what
+// at (x0, y0) (rect_focal_bounds, macro_bin_kernel); level 4: the super tile of super_f x super_f macro tiles (super_bin_kernel) -- and for EVERY triangle of the scene what
 // tile_misses_triangle decides and the interval ends it decides from, with every rounding allowance scaled by SL::scale.
 //   out[region] = 16 header floats: focal lo[3], hi[3], lmin, lmax, usable (+ 2: the focal-bound paths agree, + 4: p.tile_curv > 0, the two-level list builder is in use), A, orad[3], fc[3]
 //               + n_tris x stride floats: flags (1 keep | 2 certainly hit), det_lo, det_hi, U_lo, U_hi, V_lo, V_hi,
@@ -180,7 +180,9 @@ __global__ __launch_bounds__(256) void dbg_classify_kernel(const TraceParams p, 
   FocalBounds bb;
   bool paths_agree = true;           // level 0: focal_bounds (trace waves of large scenes) == group_focal_bounds (list builder)
   if (level == 2u) {
-    bb = macro_focal_bounds<FMA>(p, x0, y0, s_box);
+    bb = rect_focal_bounds<FMA, 4>(p, x0, y0, p.macro_w, p.macro_h, s_box);
+  } else if (level == 4u) {                          // the super tile of super_bin_kernel: every pixel of super_f x super_f macro tiles
+    bb = rect_focal_bounds<FMA, 4>(p, x0, y0, p.macro_w * p.super_f, p.macro_h * p.super_f, s_box);
   } else if (level == 3u) {                          // the 32x16 region of the two-level list builder: the union of its tiles' boxes
     FocalBounds tb;
     region_focal_bounds<FMA, SL>(p, x0 / 32u, y0 / 16u, lane, tb, bb);
@@ -448,6 +450,21 @@ hipError_t launch_dbg_hit_triangle(bool fma, uint32_t n, const float* rays, cons
   if (n == 0) return hipSuccess;
   if (fma) hipLaunchKernelGGL(dbg_hit_triangle_kernel<true>, dim3(cdiv(n, 64)), dim3(64), 0, st, n, rays, tris, eps_mode, hit, tuv, normal, point);
   else hipLaunchKernelGGL(dbg_hit_triangle_kernel<false>, dim3(cdiv(n, 64)), dim3(64), 0, st, n, rays, tris, eps_mode, hit, tuv, normal, point);
+  return hipGetLastError();
+}
+
+hipError_t launch_super_bin(const TraceParams& p, bool fma, hipStream_t st) {
+  if (p.super_lists == nullptr || p.macro_bounds == nullptr || p.macro_lists == nullptr || p.n_tris == 0u || p.rows == 0u || p.W == 0u || p.super_f == 0u ||
+      p.super_chunks != cdiv(p.n_tris, kSuperChunk) || p.super_chunks > kSuperMaxChunks) return hipErrorInvalidValue;
+  const dim3 mgrid(cdiv(p.W, p.macro_w), cdiv(p.rows, p.macro_h));
+  const dim3 sgrid(p.super_nx * cdiv(mgrid.y, p.super_f), p.super_chunks);
+  if (fma) {
+    hipLaunchKernelGGL(macro_bounds_kernel<true>, mgrid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL(super_bin_kernel<true>, sgrid, dim3(256), 0, st, p);
+  } else {
+    hipLaunchKernelGGL(macro_bounds_kernel<false>, mgrid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL(super_bin_kernel<false>, sgrid, dim3(256), 0, st, p);
+  }
   return hipGetLastError();
 }
 

@@ -8,6 +8,8 @@ namespace rtk {
 
 // Everything rt::TraceKernel receives by value (RayTracer/Kernels.cuh:110-118), for a row
 // band [row0, row0+rows) of a W x H image.
+constexpr uint32_t kSuperChunk = 1024u, kSuperMaxChunks = 64u;   // super tiles: triangles per chunk list, chunks per scene at most (rt_lists.hpp)
+
 struct TraceParams {
   float4*   render;    // rows*W RGBA float accumulators (mRenderBuffer)
   uint32_t* counts;    // rows*W sample counts          (mSampleCountBuffer)
@@ -46,6 +48,12 @@ struct TraceParams {
   // followed by macro_cap ascending triangle indices.  null = no macro level.
   uint32_t* macro_lists;
   uint32_t  macro_cap, macro_w, macro_h, macro_nx;
+  // One level above (dense scenes): super tiles of super_f x super_f macro tiles, binned by super_bin_kernel against the whole
+  // scene in chunks of 1 024 triangles (rt_lists.hpp); macro_bin_kernel then tests only its super tile's lists.  Per (super
+  // tile, chunk): count, then up to 1 024 ascending indices.  null = the macro level scans the scene.
+  uint32_t* super_lists;
+  uint32_t  super_chunks, super_f, super_nx;
+  float*    macro_bounds;   // with super_lists: 8 floats per macro tile -- focal box lo[3], hi[3], ok, any (macro_bounds_kernel)
   uint32_t* tile_lists; // small scenes: per wave tile count | winner << 10 | certain << 31, then bin_list triangle indices
                         // (written by tile_lists_kernel, read by the trace kernel); null: no lists (large scene, no triangles)
   // small scenes, split launches: this kernel traces every second block row of the band -- block row 2 * blockIdx.y + row_phase --
@@ -97,6 +105,8 @@ hipError_t launch_dbg_hit_triangle(bool fma, uint32_t n, const float* rays, cons
                                    int* hit, float* tuv, float* normal, float* point, hipStream_t st);
 bool trace_can_fuse(bool filter, bool bin);      // launches with TraceParams::iters > 1 are available
 hipError_t launch_macro_bin(const TraceParams& p, bool fma, hipStream_t st);
+// the level above: p.super_lists (before launch_macro_bin)
+hipError_t launch_super_bin(const TraceParams& p, bool fma, hipStream_t st);
 // dense scenes: the per-wave candidate lists + forms of the (half-)launch `p` into p.wave_lists (after launch_macro_bin)
 hipError_t launch_wave_lists(const TraceParams& p, bool fma, hipStream_t st);
 // one wave that does nothing for `us` microseconds (bounded): the stagger of the first split launch after the tracer was idle

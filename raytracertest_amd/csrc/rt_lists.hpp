@@ -16,17 +16,17 @@ namespace rtk {
 // conservative test as the block and wave levels, so the result stays bit-identical to the
 // full scan.  Runs once per launch (the camera may have changed): N x macro tiles tests.
 // ------------------------------------------------------------------------------------
-// Focal bounds of the pixel rectangle [x0, x0 + p.macro_w) x [y0, y0 + p.macro_h) of the band (clipped to it), by all 256
-// threads of the block: every pixel's focal point exactly as the trace kernel computes it.  s_box: 4 x 8 floats of LDS.
-template <bool FMA>
-__device__ __forceinline__ FocalBounds macro_focal_bounds(const TraceParams& p, uint32_t x0, uint32_t y0, float (*s_box)[8]) {
+// Focal bounds of the pixel rectangle [x0, x0 + rw) x [y0, y0 + rh) of the band (clipped to it), by all 64 * WAVES
+// threads of the block: every pixel's focal point exactly as the trace kernel computes it.  s_box: WAVES x 8 floats of LDS.
+template <bool FMA, int WAVES>
+__device__ __forceinline__ FocalBounds rect_focal_bounds(const TraceParams& p, uint32_t x0, uint32_t y0, uint32_t rw, uint32_t rh, float (*s_box)[8]) {
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const uint32_t x1 = (x0 + p.macro_w < p.W) ? x0 + p.macro_w : p.W;
-  const uint32_t y1 = (y0 + p.macro_h < p.rows) ? y0 + p.macro_h : p.rows;
+  const uint32_t x1 = (x0 + rw < p.W) ? x0 + rw : p.W;
+  const uint32_t y1 = (y0 + rh < p.rows) ? y0 + rh : p.rows;
   const uint32_t w = x1 - x0, count_px = w * (y1 - y0);
   float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   bool finite = true;
-  for (uint32_t i = threadIdx.x; i < count_px; i += 256u) {
+  for (uint32_t i = threadIdx.x; i < count_px; i += 64u * WAVES) {
     const uint32_t px = x0 + i % w, ly = y0 + i / w;
     V3 po, pd;
     pinhole<FMA>(p, px, p.row0 + ly, po, pd);
@@ -52,7 +52,7 @@ __device__ __forceinline__ FocalBounds macro_focal_bounds(const TraceParams& p, 
   bb.ok = true; bb.any = count_px != 0u;
 #pragma unroll
   for (int c = 0; c < 3; ++c) { bb.lo[c] = FLT_MAX; bb.hi[c] = -FLT_MAX; }
-  for (uint32_t v = 0; v < 4u; ++v) {
+  for (uint32_t v = 0; v < static_cast<uint32_t>(WAVES); ++v) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       bb.lo[c] = fminf(bb.lo[c], s_box[v][c]);
@@ -63,23 +63,20 @@ __device__ __forceinline__ FocalBounds macro_focal_bounds(const TraceParams& p, 
   return bb;
 }
 
-template <bool FMA>
-__global__ __launch_bounds__(256) void macro_bin_kernel(TraceParams p) {
-  __shared__ float s_box[4][8];
-  __shared__ uint32_t s_cnt[2][4];
+// One pass of a bin kernel (256 threads): the triangles tri_of(0 .. n) against `fam`, the survivors in ascending order to
+// out[1..], their number (0xFFFFFFFF: more than cap) to out[0].  s_cnt: 2 x 4 words of LDS.
+template <class Src>
+__device__ __forceinline__ void bin_pass(const TraceParams& p, const TileFamily& fam, Src tri_of, uint32_t n, uint32_t* out, uint32_t cap,
+                                         uint32_t (*s_cnt)[4]) {
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const FocalBounds bb = macro_focal_bounds<FMA>(p, blockIdx.x * p.macro_w, blockIdx.y * p.macro_h, s_box);
-  const TileFamily fam = make_family(p, bb);
-  uint32_t* const out = p.macro_lists + (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * (p.macro_cap + 1u);
-  const uint32_t n = p.n_tris;
   uint32_t total = 0, step = 0;
   bool overflow = false;
   for (uint32_t base = 0; base < n; base += 256u, ++step) {
-    const uint32_t tri = base + threadIdx.x;
-    const bool valid = tri < n;
-    const uint32_t ti = valid ? tri : (n - 1u);
-    const float4 A0 = p.tri_a[2u * ti], A1 = p.tri_a[2u * ti + 1u];
-    const float bz = p.tri_b[ti];
+    const uint32_t e = base + threadIdx.x;
+    const bool valid = e < n;
+    const uint32_t tri = tri_of(valid ? e : (n - 1u));
+    const float4 A0 = p.tri_a[2u * tri], A1 = p.tri_a[2u * tri + 1u];
+    const float bz = p.tri_b[tri];
     bool keep = valid;
     if (fam.usable)
       keep = valid && !tile_misses_triangle(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z});
@@ -90,13 +87,101 @@ __global__ __launch_bounds__(256) void macro_bin_kernel(TraceParams p) {
     const uint32_t c0 = slot[0], c1 = slot[1], c2 = slot[2], c3 = slot[3];
     const uint32_t before = (wave > 0u ? c0 : 0u) + (wave > 1u ? c1 : 0u) + (wave > 2u ? c2 : 0u);
     const uint32_t step_total = c0 + c1 + c2 + c3;
-    if (total + step_total > p.macro_cap) { overflow = true; break; }   // block-uniform
+    if (total + step_total > cap) { overflow = true; break; }     // block-uniform
     const uint32_t pos = total + before + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
                                                                 __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
     if (keep) out[1u + pos] = tri;                                // ascending order across waves and steps
     total += step_total;
   }
   if (threadIdx.x == 0u) out[0] = overflow ? 0xFFFFFFFFu : total;
+}
+
+// ---- the level above the macro tiles (dense scenes; TraceParams::super_lists) ------------------------------------------
+// A macro tile's list costs one test per triangle of the scene: 1 020 macro tiles x 10 000 triangles at C4, 72 M
+// instructions and -- 40 dependent steps per block -- 0.16 ms at the head of every half-launch's build chain.  Three short,
+// wide kernels instead:
+//   macro_bounds_kernel   every macro tile's focal box (all its pixels, as before) to p.macro_bounds;
+//   super_bin_kernel      a super tile = super_f x super_f macro tiles, its box the union of theirs; block (super tile, chunk)
+//                         tests the chunk's kSuperChunk triangles against the super tile's family and writes its own short
+//                         list: a super tile's list is the concatenation of its chunks' lists (ascending: so are the chunks);
+//   macro_bin_kernel      reads its box, walks its super tile's chunk lists.
+// The super tile's family contains the macro tile's, and what tile_misses_triangle drops for a family no ray of the family can
+// hit: whatever the super level drops, the macro level could only have kept in vain.
+
+__device__ __forceinline__ FocalBounds load_bounds(const float* b) {
+  FocalBounds r;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { r.lo[c] = uniform(b[c]); r.hi[c] = uniform(b[3 + c]); }
+  r.ok = uniform(b[6]) != 0.0f; r.any = uniform(b[7]) != 0.0f;
+  return r;
+}
+
+template <bool FMA>
+__global__ __launch_bounds__(256) void macro_bounds_kernel(TraceParams p) {
+  __shared__ float s_box[4][8];
+  const FocalBounds bb = rect_focal_bounds<FMA, 4>(p, blockIdx.x * p.macro_w, blockIdx.y * p.macro_h, p.macro_w, p.macro_h, s_box);
+  if (threadIdx.x == 0u) {
+    float* const o = p.macro_bounds + (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 8u;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { o[c] = bb.lo[c]; o[3 + c] = bb.hi[c]; }
+    o[6] = bb.ok ? 1.0f : 0.0f; o[7] = bb.any ? 1.0f : 0.0f;
+  }
+}
+
+template <bool FMA>
+__global__ __launch_bounds__(256) void super_bin_kernel(TraceParams p) {     // grid = (super tiles, chunks)
+  __shared__ uint32_t s_cnt[2][4];
+  const uint32_t sx = blockIdx.x % p.super_nx, sy = blockIdx.x / p.super_nx;
+  const uint32_t macro_ny = (p.rows + p.macro_h - 1u) / p.macro_h;
+  FocalBounds bb;
+  bb.ok = true; bb.any = false;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { bb.lo[c] = FLT_MAX; bb.hi[c] = -FLT_MAX; }
+  for (uint32_t j = 0; j < p.super_f; ++j) {
+    for (uint32_t i = 0; i < p.super_f; ++i) {
+      const uint32_t mx = sx * p.super_f + i, my = sy * p.super_f + j;
+      if (mx >= p.macro_nx || my >= macro_ny) continue;                  // (block-uniform)
+      const FocalBounds mb = load_bounds(p.macro_bounds + (static_cast<size_t>(my) * p.macro_nx + mx) * 8u);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { bb.lo[c] = fminf(bb.lo[c], mb.lo[c]); bb.hi[c] = fmaxf(bb.hi[c], mb.hi[c]); }
+      bb.ok = bb.ok && mb.ok; bb.any = bb.any || mb.any;
+    }
+  }
+  const TileFamily fam = make_family(p, bb);
+  const uint32_t first = blockIdx.y * kSuperChunk;
+  const uint32_t n = p.n_tris - first < kSuperChunk ? p.n_tris - first : kSuperChunk;
+  uint32_t* const out = p.super_lists + (static_cast<size_t>(blockIdx.x) * gridDim.y + blockIdx.y) * (kSuperChunk + 1u);
+  bin_pass(p, fam, [&](uint32_t e) { return first + e; }, n, out, kSuperChunk, s_cnt);
+}
+
+template <bool FMA>
+__global__ __launch_bounds__(256) void macro_bin_kernel(TraceParams p) {
+  __shared__ float s_box[4][8];
+  __shared__ uint32_t s_cnt[2][4];
+  __shared__ uint32_t s_first[kSuperMaxChunks + 1u];                    // super level: where each chunk's list starts in the concatenation
+  FocalBounds bb;
+  if (p.macro_bounds != nullptr) bb = load_bounds(p.macro_bounds + (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 8u);
+  else bb = rect_focal_bounds<FMA, 4>(p, blockIdx.x * p.macro_w, blockIdx.y * p.macro_h, p.macro_w, p.macro_h, s_box);
+  const TileFamily fam = make_family(p, bb);
+  uint32_t* const out = p.macro_lists + (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * (p.macro_cap + 1u);
+  if (p.super_lists == nullptr) {
+    bin_pass(p, fam, [](uint32_t e) { return e; }, p.n_tris, out, p.macro_cap, s_cnt);
+    return;
+  }
+  const uint32_t S = p.super_chunks;
+  const uint32_t* const sl = p.super_lists + static_cast<size_t>((blockIdx.y / p.super_f) * p.super_nx + blockIdx.x / p.super_f) * S * (kSuperChunk + 1u);
+  if (threadIdx.x == 0u) {
+    uint32_t acc = 0;
+    for (uint32_t c = 0; c < S; ++c) { s_first[c] = acc; acc += sl[static_cast<size_t>(c) * (kSuperChunk + 1u)]; }
+    s_first[S] = acc;
+  }
+  __syncthreads();
+  const uint32_t n = s_first[S];
+  bin_pass(p, fam, [&](uint32_t e) {
+    uint32_t c = 0;
+    for (uint32_t k = 1; k < S; ++k) c += (e >= s_first[k]) ? 1u : 0u;   // (the chunks' starts ascend)
+    return sl[static_cast<size_t>(c) * (kSuperChunk + 1u) + 1u + (e - s_first[c])];
+  }, n, out, p.macro_cap, s_cnt);
 }
 
 // ------------------------------------------------------------------------------------

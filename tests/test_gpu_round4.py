@@ -269,3 +269,31 @@ def test_dense_launch_machinery_soak(rt):
     import subprocess, sys
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_dense.py"), "50", "11"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "soak_dense ok: 50 phases" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_super_tiles_change_no_word_and_only_shorten_the_macro_level(rt):
+    """Dense scenes bin the triangles per super tile (4 x 4 macro tiles, super_bin_kernel) before the macro tiles: the C4
+    scene at 1920x1080x8 spp with the level and without it (RT_FLAG_NO_SUPER_BINS), lists rebuilt and kept, all four buffers;
+    the per-tile candidate counts are the same."""
+    from raytracertest_amd import scenes
+    cfg = scenes.CONFIGS["C4"]
+    tris, _ = scenes.scene_for("C4")
+
+    def run(**kw):
+        g = rt.RayTracer((1920, 1080), (0, 0, 0), cfg["angles"], cfg["fov"], cfg["focal"], cfg["aperture"], seed=cfg["seed"], **kw)
+        assert g.UploadScene(tris)
+        g.SetListReuse(False)
+        g.TraceEnqueue(1, 8); g.Sync()
+        g.SetListReuse(True)
+        g.TraceEnqueue(2, 4); g.Sync()                        # lists kept
+        g.RotateCamera((0.05, -0.02))                         # a new view: every level rebuilds
+        g.TraceEnqueue(1, 8); g.Sync()
+        out = buffers(g)
+        counts = [g.DebugWaveListCounts(h) for h in (0, 1)]
+        g.close()
+        return out, counts
+    (a, ca), (b, cb) = run(), run(no_super_bins=True)
+    for name, x, y in zip(("render", "counts", "rng", "image"), a, b):
+        assert np.array_equal(np.ascontiguousarray(x).view(np.uint32), np.ascontiguousarray(y).view(np.uint32)), name
+    for (x, capx), (y, capy) in zip(ca, cb):
+        assert capx == capy and x.size > 0 and np.array_equal(x, y)

@@ -5,9 +5,11 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracertest_amd as R
 from raytracertest_amd import api, scenes
-name = sys.argv[1] if len(sys.argv) > 1 else "C4"
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+name = args[0] if args else "C4"
+kw = {"no_super_bins": True} if "--no-super" in sys.argv else {}
 cfg = scenes.CONFIGS[name]; tris, _ = scenes.scene_for(name)
-g = R.RayTracer((cfg["width"], cfg["height"]), (0, 0, 0), cfg["angles"], cfg["fov"], cfg["focal"], cfg["aperture"], seed=1)
+g = R.RayTracer((cfg["width"], cfg["height"]), (0, 0, 0), cfg["angles"], cfg["fov"], cfg["focal"], cfg["aperture"], seed=1, **kw)
 g.UploadScene(tris)
 t0 = time.perf_counter()
 while time.perf_counter() - t0 < 0.15: api.dbg_valu_peak(0)
