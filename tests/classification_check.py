@@ -295,7 +295,7 @@ def run(g, o, regions, level, lens, *, forms=False, ladder=LADDER, max_pixels=No
     """Check `regions` [(x0, y0) band-local] of tracer `g` (api.RayTracer) against oracle tracer `o` (same scene, camera,
     frame).  stored: g.DebugTileListWords() to cross-check the product's own lists (level 0, small scenes).  -> Tally"""
     regions = np.ascontiguousarray(regions, np.uint32).reshape(-1, 2)
-    rw, rh = {0: (8, 8), 1: (32, 8), 2: (128, 64), 3: (32, 16)}[level]
+    rw, rh = {0: (8, 8), 1: (32, 8), 2: (128, 64), 3: (32, 16), 4: (512, 256)}[level]      # 4: a super tile of 4 x 4 macro tiles
     out = {s: g.DebugClassify(regions, level, forms, s) for s in ladder}
     if level == 3 and not (int(out[ladder[0]][0][0][8]) & 4):
         return Tally()                                      # the two-level list builder is not in use for this camera / frame

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Campaign form of tests/test_gpu_classification.py: N adversarial + N/2 cover configurations, every tile x every triangle
-(small scenes) or sampled regions of all three levels (large scenes, with the per-sample forms), against the reference's own
+(small scenes) or sampled regions of all levels (large scenes, with the per-sample forms), against the reference's own
 per-ray arithmetic (tests/classification_check.py).  Prints and writes the margin record: violations per allowance scale,
 the smallest passing scale, and how far the reference's values reach into the allowances ("needed scale").
 Usage: classification_margin.py [N] [seed] [out.json] [share of the adversarial configurations that are dense scenes, default 0.04]"""
@@ -23,7 +23,7 @@ rng = np.random.default_rng(seed)
 lens = cc.lens_samples(orc, seed=seed, pixel_index=3)
 small = np.concatenate([lens[:1], lens[1:113:2], lens[-8:]])
 tallies = {"small_scenes": cc.Tally(), "cover_scenes": cc.Tally(), "small_scenes_region_level": cc.Tally(), "large_scenes_wave_forms": cc.Tally(),
-           "large_scenes_block": cc.Tally(), "large_scenes_macro": cc.Tally()}
+           "large_scenes_block": cc.Tally(), "large_scenes_macro": cc.Tally(), "large_scenes_super": cc.Tally()}
 t0 = time.time()
 for it in range(N + N // 2):
     kind = "adv" if it < N else "cover"
@@ -45,6 +45,7 @@ for it in range(N + N // 2):
         pick = [blocks[i] for i in rng.choice(len(blocks), min(3, len(blocks)), replace=False)]
         tallies["large_scenes_block"].merge(cc.run(g, o, pick, 1, small, ladder=(1000, 100, 0), tag=tag))
         tallies["large_scenes_macro"].merge(cc.run(g, o, [(0, 0)], 2, small, ladder=(1000, 100, 0), max_pixels=256, tag=tag))
+        tallies["large_scenes_super"].merge(cc.run(g, o, [(0, 0)], 4, small, ladder=(1000, 100, 0), max_pixels=256, tag=tag))   # (4 x 4 macro tiles, clipped by the frame)
     else:
         stored = None
         if n <= 256:

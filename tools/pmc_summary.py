@@ -13,7 +13,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, src = sys.argv[1], sys.argv[2]
 out = os.path.join(root, "gpurun_out", tag)
 dst = os.path.join(root, "profiles")
-PATH_KERNELS = ("trace_kernel", "lists_kernel", "macro_bin_kernel")
+PATH_KERNELS = ("trace_kernel", "lists_kernel", "macro_bin_kernel", "macro_bounds_kernel", "super_bin_kernel")
 
 
 def newest(pattern):
