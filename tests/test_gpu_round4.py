@@ -297,3 +297,28 @@ def test_super_tiles_change_no_word_and_only_shorten_the_macro_level(rt):
         assert np.array_equal(np.ascontiguousarray(x).view(np.uint32), np.ascontiguousarray(y).view(np.uint32)), name
     for (x, capx), (y, capy) in zip(ca, cb):
         assert capx == capy and x.size > 0 and np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("n_tris,size,macro_cap", [(3000, (1024, 640), None), (60000, (768, 512), None), (5000, (1024, 576), "40"),
+                                                   (2048, (1152, 256), None)])
+def test_super_tiles_beside_every_kind_of_macro_consumer(rt, monkeypatch, n_tris, size, macro_cap):
+    """The super level feeds the macro tiles of every large-scene launch, not only the dense scenes with lists in HBM: 3 000
+    triangles (classification inside the trace kernel, no forms), 60 000 (59 chunks, multi-round wave lists), macro lists that
+    overflow their capacity (the consumers scan the scene), a frame of one row of super tiles with exactly two chunks -- default
+    == without the super level == the reference's full scan, render and RNG states."""
+    from raytracertest_amd import scenes
+    scn = scenes.random_triangles(n_tris, 4242 + n_tris)
+    if macro_cap is not None:
+        monkeypatch.setenv("RT_MI355X_MACRO_CAP", macro_cap)
+
+    def run(**kw):
+        g = rt.RayTracer(size, (0, 0, 0), (0.03, -0.02), 70.0, 3.0, 0.05, seed=5, **kw)
+        assert g.UploadScene(scn)
+        g.Trace(2, 3, 0); assert g.Wait()
+        out = (g.RenderBuffer().view(np.uint32).copy(), g.RngStates().copy())
+        g.close()
+        return out
+    ref = run(no_binning=True)
+    for kw in (dict(), dict(no_super_bins=True)):
+        got = run(**kw)
+        assert np.array_equal(ref[0], got[0]) and np.array_equal(ref[1], got[1]), kw
