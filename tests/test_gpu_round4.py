@@ -322,3 +322,19 @@ def test_super_tiles_beside_every_kind_of_macro_consumer(rt, monkeypatch, n_tris
     for kw in (dict(), dict(no_super_bins=True)):
         got = run(**kw)
         assert np.array_equal(ref[0], got[0]) and np.array_equal(ref[1], got[1]), kw
+
+
+def test_dense_scene_at_8k_equals_the_full_scan(rt):
+    """Beyond the BASELINE sizes: 7680x4320 (33 M pixels, 518 400 tiles, 2.8 GB of list slots per half), the C4 scene at 4 spp --
+    the default launch (super / macro / block / wave lists in HBM) == the reference's full scan, CRC32 of all four buffers."""
+    import zlib
+    from raytracertest_amd import scenes
+    scn = scenes.random_triangles(10000, 12345)
+    crcs = []
+    for kw in (dict(), dict(no_binning=True)):
+        g = rt.RayTracer((7680, 4320), (0, 0, 0), (0.02, -0.01), 70.0, 3.0, 0.05, seed=3, **kw)
+        assert g.UploadScene(scn)
+        g.TraceEnqueue(1, 4); g.Sync()
+        crcs.append([zlib.crc32(np.ascontiguousarray(b).tobytes()) for b in (g.RenderBuffer(), g.SampleCounts(), g.RngStates(), g.Image())])
+        g.close()
+    assert crcs[0] == crcs[1]
