@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak of the dense-scene launch machinery (macro lists + per-wave lists in HBM, keyed and kept; split and unsplit launches;
 fused iterations) against the same operations on a full-scan tracer (RT_FLAG_NO_BINNING: every ray x every triangle, no lists at
-all): random TraceEnqueue / Launch / Trace with an update cadence, camera swings and lens changes, scene swaps between dense,
+all; frames wide enough for the super tiles now and then): random TraceEnqueue / Launch / Trace with an update cadence, camera swings and lens changes, scene swaps between dense,
 mid-size and small scenes, Resize, list reuse on and off, launches in flight in between.  Every phase: all four buffers bit for bit.
   python tools/soak_dense.py [phases] [seed]"""
 import os, sys
@@ -41,7 +41,10 @@ for ph in range(phases):
         fov, foc, ap = float(rng.uniform(50, 80)), float(rng.uniform(2, 5)), float(rng.choice([0.0, 0.02, 0.05, 0.2]))
         for t in both: t.SetCameraParameters(fov, foc, ap)
     elif r < 0.48:
-        W, H = int(rng.integers(64, 420)), int(rng.integers(40, 300))
+        if rng.random() < 0.3:                              # wide enough for the super tiles above the macro tiles (> 16 macro tiles)
+            W, H = int(rng.integers(600, 1100)), int(rng.integers(260, 420))
+        else:
+            W, H = int(rng.integers(64, 420)), int(rng.integers(40, 300))
         for t in both: t.Resize((W, H))
     elif r < 0.56:
         reuse = bool(rng.integers(0, 2))
