@@ -529,6 +529,12 @@ hipError_t launch_sure_table(const float4* colors, uint32_t n_tris, uint32_t sam
 
 hipError_t launch_tile_lists(const TraceParams& p, bool fma, hipStream_t st) {
   if (p.tile_lists == nullptr || p.rows == 0u || p.W == 0u) return hipSuccess;
+  if (p.tile_curv > 0.0f && p.n_tris <= 32u && p.n_tris != 0u) {   // two levels, two regions per wave
+    const dim3 grid(cdiv(cdiv(p.W, 32) * cdiv(cdiv(p.rows, 8), 2), 8u));
+    if (fma) hipLaunchKernelGGL((region_pair_lists_kernel<true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((region_pair_lists_kernel<false>), grid, dim3(256), 0, st, p);
+    return hipGetLastError();
+  }
   if (p.tile_curv > 0.0f && p.n_tris <= 256u) {             // two levels: region -> tiles (its LDS candidate list holds 256)
     const dim3 grid(cdiv(cdiv(p.W, 32) * cdiv(cdiv(p.rows, 8), 2), 4u));
     if (fma) hipLaunchKernelGGL((region_lists_kernel<true>), grid, dim3(256), 0, st, p);

@@ -413,7 +413,8 @@ __device__ __forceinline__ void region_corner_pixel(const TraceParams& p, uint32
 }
 
 // Focal boxes of the 8 tiles of region (rx, ry) -- in lanes 4 t .. 4 t + 3 of both half-waves -- and their union (every lane).
-template <bool FMA, class SL>
+// PACK: the two half-waves own different regions (rx, ry differ between them): every quantity is taken per half-wave.
+template <bool FMA, class SL, bool PACK = false>
 __device__ __forceinline__ void region_focal_bounds(const TraceParams& p, uint32_t rx, uint32_t ry, uint32_t lane,
                                                     FocalBounds& tile_b, FocalBounds& region_b) {
   const uint32_t l32 = lane & 31u;
@@ -440,12 +441,13 @@ __device__ __forceinline__ void region_focal_bounds(const TraceParams& p, uint32
   }
   // (a NaN corner makes lo/hi of its quad NaN-free through fmin/fmax: the corners themselves are asked, quad-wide)
   const unsigned long long badm = __builtin_amdgcn_ballot_w64(!fin);
-  const uint32_t quad_bad = (static_cast<uint32_t>(badm >> (lane & 28u)) & 0xFu);                 // lanes 0..31 mirror 32..63
+  const uint32_t quad_bad = (static_cast<uint32_t>(badm >> (lane & (PACK ? 60u : 28u))) & 0xFu);   // (!PACK: lanes 0..31 mirror 32..63)
   tile_b.ok = quad_bad == 0u;
   tile_b.any = valid;
   const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
-  region_b.any = (vm & 0xFFFFFFFFull) != 0ull;
-  region_b.ok = ((badm & vm) & 0xFFFFFFFFull) == 0ull;
+  const uint32_t hs = PACK ? (lane & 32u) : 0u;                                                   // this half-wave's bits
+  region_b.any = ((vm >> hs) & 0xFFFFFFFFull) != 0ull;
+  region_b.ok = (((badm & vm) >> hs) & 0xFFFFFFFFull) == 0ull;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     region_b.lo[i] = group_min<32>(rlo[i]);
@@ -454,12 +456,99 @@ __device__ __forceinline__ void region_focal_bounds(const TraceParams& p, uint32
 }
 
 
-// 8-lane groups: max in every lane of the group (quad_perm x 2, row_half_mirror)
-__device__ __forceinline__ float max8(float v) {
+// G-lane groups (G = 8 or 4): max in every lane of the group (quad_perm x 2, row_half_mirror)
+template <int G>
+__device__ __forceinline__ float max_group(float v) {
   v = fmaxf(v, dpp_f<0xB1>(v));
   v = fmaxf(v, dpp_f<0x4E>(v));
-  v = fmaxf(v, dpp_f<0x141>(v));
+  if constexpr (G == 8) v = fmaxf(v, dpp_f<0x141>(v));
   return v;
+}
+
+// Level 2 of the region builder: G2 candidates per pass against the family of the tile this lane's G2-lane group owns, with the
+// certain-winner bounds; per-tile compaction, the running winner / top-two bookkeeping of tile_lists_kernel, the list and its
+// header word to the tile's slot.  mine: the tile's focal box; cand / cnt: the candidate list of the tile's REGION (the same in
+// every lane of a group; cnt_max >= cnt wave-uniform: the trip count); tslot / slot_live / lower: where the tile's list goes.
+template <class SL, int G2>
+__device__ __forceinline__ void region_level2(const TraceParams& p, uint32_t lane, const FocalBounds& mine, const uint32_t* cand, uint32_t cnt,
+                                              uint32_t cnt_max, uint32_t tslot, bool slot_live, bool lower) {
+  constexpr uint32_t GM = (1u << G2) - 1u;
+  const uint32_t j = lane & (G2 - 1u), gsh = lane & ~static_cast<uint32_t>(G2 - 1);              // slot within the group, its first lane
+  const bool tile_valid = mine.any;                                  // the tile has pixels in the band
+  const TileFamily fam = make_family<SL>(p, mine);
+  uint32_t* const saved = p.tile_lists + static_cast<size_t>(tile_valid ? tslot : 0u) * (1u + p.bin_list);
+  const float NEG = -__builtin_inff();
+  uint32_t count = 0;
+  bool haveA = false;
+  float Q = NEG, M1 = NEG, M2 = NEG;
+  uint32_t A = 0, I1 = 0xFFFFFFFFu;
+  const bool one_pass = cnt_max <= static_cast<uint32_t>(G2);        // every candidate of the region has a lane: pairs can be compared
+  bool others_ok = true;                                             // one_pass: every other kept triangle is certainly nearer than A
+  for (uint32_t c0 = 0; c0 < cnt_max; c0 += G2) {                    // (wave-uniform trip count)
+    const bool has = tile_valid && c0 + j < cnt;
+    const uint32_t tri = (c0 + j < cnt) ? cand[c0 + j] : 0u;         // (a lane without a candidate takes triangle 0: n_tris >= 1 here)
+    const float4 A0 = p.tri_a[2u * tri], A1 = p.tri_a[2u * tri + 1u];
+    const float bz = p.tri_b[tri];
+    bool keep = has, sure = false;
+    float q[2] = {0.0f, 0.0f};
+    float pr[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (fam.usable) {
+      const bool miss = tile_misses_triangle<false, true, SL>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z}, nullptr, &sure, q,
+                                                              nullptr, pr);
+      keep = has && !miss;
+    }
+    const uint32_t gm = static_cast<uint32_t>(__builtin_amdgcn_ballot_w64(keep) >> gsh) & GM;
+    const uint32_t pos = count + static_cast<uint32_t>(__builtin_popcount(gm & ((1u << j) - 1u)));
+    if (keep) saved[1u + pos] = tri;                                 // ascending: candidates and passes ascend
+    count += static_cast<uint32_t>(__builtin_popcount(gm));
+    const bool cd = keep && sure && fam.usable;
+    const float Qs = max_group<G2>(cd ? q[0] : NEG);
+    const uint32_t gbm = static_cast<uint32_t>(__builtin_amdgcn_ballot_w64(cd && q[0] == Qs) >> gsh) & GM;
+    if (gbm != 0u && (!haveA || Qs > Q)) { haveA = true; Q = Qs; A = cand[c0 + static_cast<uint32_t>(__builtin_ctz(gbm))]; }
+    const float qh = keep ? ((q[1] == q[1]) ? q[1] : __builtin_inff()) : NEG;
+    if (one_pass) {
+      // A's rivals one by one: nearer by the q intervals, or -- where those overlap -- by the pairwise bound (pair_farther)
+      const uint32_t la = gbm != 0u ? static_cast<uint32_t>(__builtin_ctz(gbm)) : 0xFFFFFFFFu;
+      bool lane_ok = !keep || j == la || (gbm != 0u && qh < Qs - 1e-4f * (__builtin_fabsf(qh) + __builtin_fabsf(Qs)));
+      const bool need = gbm != 0u && !lane_ok;
+      if (__builtin_amdgcn_ballot_w64(need) != 0ull) {               // (wave-uniform: rare)
+        float pa[9];
+        const int src = static_cast<int>(gsh + (la & (G2 - 1u)));
+#pragma unroll
+        for (int i = 0; i < 9; ++i) pa[i] = __shfl(pr[i], src, 64);
+        lane_ok = lane_ok || (need && pair_farther<SL>(fam, pa, pr));
+      }
+      others_ok = (static_cast<uint32_t>(__builtin_amdgcn_ballot_w64(!lane_ok) >> gsh) & GM) == 0u;
+    }
+    const float m1s = max_group<G2>(qh);
+    const uint32_t gtm = static_cast<uint32_t>(__builtin_amdgcn_ballot_w64(keep && qh == m1s) >> gsh) & GM;
+    const uint32_t l1 = gtm != 0u ? static_cast<uint32_t>(__builtin_ctz(gtm)) : 0xFFFFFFFFu;
+    const float m2s = max_group<G2>((keep && j != l1) ? qh : NEG);
+    if (gtm != 0u) {
+      const uint32_t i1s = cand[c0 + l1];
+      if (m1s > M1) { M2 = fmaxf(M1, m2s); M1 = m1s; I1 = i1s; }
+      else { M2 = fmaxf(M2, m1s); }
+    }
+  }
+  bool sure_one = false;
+  if (haveA) {
+    const float R = (I1 == A) ? M2 : M1;                             // the largest upper bound among the OTHER kept triangles
+    sure_one = count <= 1u || (R < Q - 1e-4f * (__builtin_fabsf(R) + __builtin_fabsf(Q)));
+    if (one_pass) sure_one = sure_one || others_ok;                  // (others_ok alone would do: the line above is what it generalises)
+  }
+  if (j == 0u) {
+    if (tile_valid) saved[0] = count | (A << 10) | (sure_one ? 0x80000000u : 0u);
+    else if (slot_live) p.tile_lists[static_cast<size_t>(tslot) * (1u + p.bin_list)] = 0u;
+  }
+  if (p.half_cost != nullptr) {                                      // tiles that will generate rays, per half of the band
+    const bool rays = j == 0u && tile_valid && !sure_one;
+    const uint32_t nu = static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(rays && !lower)));
+    const uint32_t nl = static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(rays && lower)));
+    if (lane == 0u) {
+      if (nu != 0u) atomicAdd(p.half_cost, nu);
+      if (nl != 0u) atomicAdd(p.half_cost + 1, nl);
+    }
+  }
 }
 
 template <bool FMA, class SL = SlackProduct>
@@ -497,7 +586,7 @@ __global__ __launch_bounds__(256, RT_LISTS_WAVES) void region_lists_kernel(const
   }
 
   // ---- level 2: 8 candidates x the 8 tiles, lane = tile * 8 + candidate slot ---------------------------------------------
-  const uint32_t t8 = lane >> 3, j = lane & 7u;
+  const uint32_t t8 = lane >> 3;
   FocalBounds mine;                                                  // tile t8's box: from lane 4 * t8
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -507,83 +596,85 @@ __global__ __launch_bounds__(256, RT_LISTS_WAVES) void region_lists_kernel(const
   const unsigned long long okm = __builtin_amdgcn_ballot_w64(tb.ok), anym = __builtin_amdgcn_ballot_w64(tb.any);
   mine.ok = ((okm >> (4u * t8)) & 1ull) != 0ull;
   mine.any = ((anym >> (4u * t8)) & 1ull) != 0ull;
-  const bool tile_valid = mine.any;                                  // the tile has pixels in the band
-  const TileFamily fam = make_family<SL>(p, mine);
-  const uint32_t tslot = ((ry * 2u + (t8 >> 2)) * gx + rx) * 4u + (t8 & 3u);
-  uint32_t* const saved = p.tile_lists + static_cast<size_t>(tile_valid ? tslot : 0u) * (1u + p.bin_list);
-  const bool slot_live = (ry * 2u + (t8 >> 2)) < gy;                 // (a slot right of the image exists and gets an empty list)
-  const float NEG = -__builtin_inff();
-  uint32_t count = 0;
-  bool haveA = false;
-  float Q = NEG, M1 = NEG, M2 = NEG;
-  uint32_t A = 0, I1 = 0xFFFFFFFFu;
-  const uint32_t gsh = lane & 56u;                                   // first lane of this 8-lane group
-  const bool one_pass = cnt <= 8u;                                   // every candidate of the region has a lane: pairs can be compared
-  bool others_ok = true;                                             // one_pass: every other kept triangle is certainly nearer than A
-  for (uint32_t c0 = 0; c0 < cnt; c0 += 8u) {                        // (wave-uniform trip count)
-    const bool has = tile_valid && c0 + j < cnt;
-    const uint32_t tri = cand[(c0 + j < cnt) ? c0 + j : 0u];
-    const float4 A0 = p.tri_a[2u * tri], A1 = p.tri_a[2u * tri + 1u];
-    const float bz = p.tri_b[tri];
-    bool keep = has, sure = false;
-    float q[2] = {0.0f, 0.0f};
-    float pr[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    if (fam.usable) {
-      const bool miss = tile_misses_triangle<false, true, SL>(fam, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z}, nullptr, &sure, q,
-                                                              nullptr, pr);
-      keep = has && !miss;
-    }
-    const uint32_t gm = static_cast<uint32_t>(__builtin_amdgcn_ballot_w64(keep) >> gsh) & 0xFFu;
-    const uint32_t pos = count + static_cast<uint32_t>(__builtin_popcount(gm & ((1u << j) - 1u)));
-    if (keep) saved[1u + pos] = tri;                                 // ascending: candidates and passes ascend
-    count += static_cast<uint32_t>(__builtin_popcount(gm));
-    const bool cd = keep && sure && fam.usable;
-    const float Qs = max8(cd ? q[0] : NEG);
-    const uint32_t gbm = static_cast<uint32_t>(__builtin_amdgcn_ballot_w64(cd && q[0] == Qs) >> gsh) & 0xFFu;
-    if (gbm != 0u && (!haveA || Qs > Q)) { haveA = true; Q = Qs; A = cand[c0 + static_cast<uint32_t>(__builtin_ctz(gbm))]; }
-    const float qh = keep ? ((q[1] == q[1]) ? q[1] : __builtin_inff()) : NEG;
-    if (one_pass) {
-      // A's rivals one by one: nearer by the q intervals, or -- where those overlap -- by the pairwise bound (pair_farther)
-      const uint32_t la = gbm != 0u ? static_cast<uint32_t>(__builtin_ctz(gbm)) : 0xFFFFFFFFu;
-      bool lane_ok = !keep || j == la || (gbm != 0u && qh < Qs - 1e-4f * (__builtin_fabsf(qh) + __builtin_fabsf(Qs)));
-      const bool need = gbm != 0u && !lane_ok;
-      if (__builtin_amdgcn_ballot_w64(need) != 0ull) {               // (wave-uniform: rare)
-        float pa[9];
-        const int src = static_cast<int>(gsh + (la & 7u));
+  const uint32_t brow = ry * 2u + (t8 >> 2);
+  region_level2<SL, 8>(p, lane, mine, cand, cnt, cnt, (brow * gx + rx) * 4u + (t8 & 3u), brow < gy, brow >= p.cost_split_brow);
+}
+
+// ------------------------------------------------------------------------------------
+// Scenes of up to 32 triangles (C3): the same two levels with TWO regions per wave.  Level 1 uses half of a wave's lanes there
+// (lane = triangle) and level 2 three of its eight candidate slots per tile (a C3 region keeps ~3 of the 32 triangles):
+//   1. lanes 0..31 own region 2 w, lanes 32..63 region 2 w + 1: one pinhole pass for both regions' 64 tile corners;
+//   2. level 1, lane = region half * 32 + triangle, per-half compaction into the half's candidate list;
+//   3. level 2 with FOUR slots per tile, lane = tile * 4 + slot over the 16 tiles of both regions, when neither region keeps more
+//      than four candidates (every candidate has a lane: the pairwise certain-winner bound applies as with eight); else the
+//      eight-slot pass of region_lists_kernel for one region after the other.
+// Verdict calls, their inputs and the order of the survivors are those of region_lists_kernel: the same lists and header words.
+// grid = ceil(regions / 8) blocks of 256 threads.
+// ------------------------------------------------------------------------------------
+template <bool FMA, class SL = SlackProduct>
+// (116 VGPRs, four waves per SIMD: held to 96 for five it spills 84 bytes per lane and the step costs 57.9 instead of 57.3 us)
+__global__ __launch_bounds__(256, 4) void region_pair_lists_kernel(const TraceParams p) {
+  __shared__ uint32_t s_cand[4][2][32];                             // per wave and half: the region's candidates, ascending
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, half = lane >> 5;
+  const uint32_t gx = (p.W + 31u) / 32u, gy = (p.rows + 7u) / 8u, gry = (gy + 1u) / 2u, regions = gx * gry;
+  const uint32_t first = (blockIdx.x * 4u + wave) * 2u;
+  if (first >= regions) return;                                     // wave-uniform
+  const bool live = first + half < regions;                         // (the last wave may own one region only)
+  const uint32_t region = live ? first + half : first;              // a half without a region shadows the other one and writes nothing
+  const uint32_t rx = region % gx, ry = region / gx;
+  FocalBounds tb, rb;
+  region_focal_bounds<FMA, SL, true>(p, rx, ry, lane, tb, rb);
+  const uint32_t n = p.n_tris;                                       // <= 32 (host)
+  uint32_t* const cand = s_cand[wave][half];
+
+  // ---- level 1, lane = half * 32 + triangle
+  uint32_t cnt;
+  {
+    const TileFamily rf = make_family<SL>(p, rb);
+    const uint32_t tri = lane & 31u;
+    const bool valid = tri < n;
+    const uint32_t ti = valid ? tri : n - 1u;
+    const float4 A0 = p.tri_a[2u * ti], A1 = p.tri_a[2u * ti + 1u];
+    const float bz = p.tri_b[ti];
+    bool keep = valid;
+    if (rf.usable) keep = valid && !tile_misses_triangle<false, false, SL>(rf, {A1.z, A1.w, bz}, {A0.w, A1.x, A1.y}, {A0.x, A0.y, A0.z});
+    const uint32_t hm = static_cast<uint32_t>(__builtin_amdgcn_ballot_w64(keep) >> (lane & 32u));   // this half's survivors
+    if (keep) cand[__builtin_popcount(hm & ((1u << tri) - 1u))] = tri;
+    cnt = static_cast<uint32_t>(__builtin_popcount(hm));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // this wave's ds_writes before its ds_reads
+    __builtin_amdgcn_wave_barrier();
+  }
+  const uint32_t cnt_a = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cnt), 0));
+  const uint32_t cnt_b = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cnt), 32));
+  const unsigned long long okm = __builtin_amdgcn_ballot_w64(tb.ok), anym = __builtin_amdgcn_ballot_w64(tb.any && live);
+
+  if (cnt_a <= 4u && cnt_b <= 4u) {
+    // ---- level 2, four slots per tile: lane = tile * 4 + slot, tiles 0..7 of region A, 8..15 of region B (lanes 4 t .. 4 t + 3
+    //      hold tile t's box already)
+    const uint32_t t8 = (lane >> 2) & 7u;
+    FocalBounds mine = tb;
+    mine.ok = ((okm >> (lane & 60u)) & 1ull) != 0ull;
+    mine.any = ((anym >> (lane & 60u)) & 1ull) != 0ull;
+    const uint32_t brow = ry * 2u + (t8 >> 2);
+    region_level2<SL, 4>(p, lane, mine, cand, cnt, cnt_a > cnt_b ? cnt_a : cnt_b, (brow * gx + rx) * 4u + (t8 & 3u), live && brow < gy,
+                         brow >= p.cost_split_brow);
+  } else {
+    // ---- level 2 as region_lists_kernel runs it, one region after the other
+#pragma nounroll
+    for (uint32_t h = 0; h < 2u; ++h) {
+      if (first + h >= regions) break;                               // wave-uniform
+      const uint32_t t8 = lane >> 3, src = h * 32u + 4u * t8;
+      FocalBounds mine;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) pa[i] = __shfl(pr[i], src, 64);
-        lane_ok = lane_ok || (need && pair_farther<SL>(fam, pa, pr));
+      for (int i = 0; i < 3; ++i) {
+        mine.lo[i] = __shfl(tb.lo[i], static_cast<int>(src), 64);
+        mine.hi[i] = __shfl(tb.hi[i], static_cast<int>(src), 64);
       }
-      others_ok = (static_cast<uint32_t>(__builtin_amdgcn_ballot_w64(!lane_ok) >> gsh) & 0xFFu) == 0u;
-    }
-    const float m1s = max8(qh);
-    const uint32_t gtm = static_cast<uint32_t>(__builtin_amdgcn_ballot_w64(keep && qh == m1s) >> gsh) & 0xFFu;
-    const uint32_t l1 = gtm != 0u ? static_cast<uint32_t>(__builtin_ctz(gtm)) : 0xFFFFFFFFu;
-    const float m2s = max8((keep && j != l1) ? qh : NEG);
-    if (gtm != 0u) {
-      const uint32_t i1s = cand[c0 + l1];
-      if (m1s > M1) { M2 = fmaxf(M1, m2s); M1 = m1s; I1 = i1s; }
-      else { M2 = fmaxf(M2, m1s); }
-    }
-  }
-  bool sure_one = false;
-  if (haveA) {
-    const float R = (I1 == A) ? M2 : M1;                             // the largest upper bound among the OTHER kept triangles
-    sure_one = count <= 1u || (R < Q - 1e-4f * (__builtin_fabsf(R) + __builtin_fabsf(Q)));
-    if (one_pass) sure_one = sure_one || others_ok;                  // (others_ok alone would do: the line above is what it generalises)
-  }
-  if (j == 0u) {
-    if (tile_valid) saved[0] = count | (A << 10) | (sure_one ? 0x80000000u : 0u);
-    else if (slot_live) p.tile_lists[static_cast<size_t>(tslot) * (1u + p.bin_list)] = 0u;
-  }
-  if (p.half_cost != nullptr) {                                      // tiles that will generate rays, per half of the band
-    const bool rays = j == 0u && tile_valid && !sure_one;
-    const bool lower = (ry * 2u + (t8 >> 2)) >= p.cost_split_brow;
-    const uint32_t nu = static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(rays && !lower)));
-    const uint32_t nl = static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(rays && lower)));
-    if (lane == 0u) {
-      if (nu != 0u) atomicAdd(p.half_cost, nu);
-      if (nl != 0u) atomicAdd(p.half_cost + 1, nl);
+      mine.ok = ((okm >> src) & 1ull) != 0ull;
+      mine.any = ((anym >> src) & 1ull) != 0ull;
+      const uint32_t hrx = (first + h) % gx, hry = (first + h) / gx, brow = hry * 2u + (t8 >> 2);
+      const uint32_t hc = h == 0u ? cnt_a : cnt_b;
+      region_level2<SL, 8>(p, lane, mine, s_cand[wave][h], hc, hc, (brow * gx + hrx) * 4u + (t8 & 3u), brow < gy, brow >= p.cost_split_brow);
     }
   }
 }
