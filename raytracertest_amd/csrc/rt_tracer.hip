@@ -712,6 +712,7 @@ struct rt_tracer {
   hipEvent_t list_free_a[kFreeEvents] = {}, list_free_b[kFreeEvents] = {};
   uint64_t list_free_build[kFreeEvents] = {};   // the build index each pair was recorded at (0 = never)
   uint64_t list_alloc_build = 0;      // builds before this one wrote buffers that no longer exist
+  uint64_t list_free_waited = 0;      // the build index of the free-event pair stream_l waited for last
   int list_cur = 0;                   // slot of the current lists
   uint64_t list_builds = 0;           // builds so far; the trace streams remember which one they have waited for
   uint64_t list_waited_a = 0, list_waited_b = 0;
@@ -837,8 +838,11 @@ struct rt_tracer {
       const uint64_t e = ((m - ring_n + 1 + kFreeStride - 1) / kFreeStride) * kFreeStride;   // oldest record that covers build m - ring_n
       const int i = static_cast<int>((e / kFreeStride) % kFreeEvents);
       if (list_free_build[i] != e) throw HipFail{"list ring: the free event of the slot's readers is missing"};
-      HIP_CHECK(hipStreamWaitEvent(stream_l, list_free_a[i], 0));
-      HIP_CHECK(hipStreamWaitEvent(stream_l, list_free_b[i], 0));
+      if (e != list_free_waited) {                                     // (kFreeStride builds in a row need the same pair: stream_l has it behind it already)
+        HIP_CHECK(hipStreamWaitEvent(stream_l, list_free_a[i], 0));
+        HIP_CHECK(hipStreamWaitEvent(stream_l, list_free_b[i], 0));
+        list_free_waited = e;
+      }
     }
     list_cur = r;
     rtk::TraceParams q = p_band;
